@@ -1,0 +1,260 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X per-pixel Monte-Carlo rendering path.
+ *
+ * This is the drop-in boundary for the reference's row fan-out
+ *   /root/reference/src/render/integrator.rs:226-243
+ *   (bands.into_par_iter()...for_each(render_line))
+ * i.e. everything `RenderIntegrator::render` does AFTER it has built the
+ * camera, the element list, the BVH and the attractor list
+ * (integrator.rs:161-206).  The host keeps scene loading and the BVH build;
+ * the library takes plain-old-data copies of those structures and fills the
+ * two pixel buffers `render_line` fills (integrator.rs:331,337).
+ *
+ * Plain C, no C++ types, no exceptions/unwinding across the boundary.  All
+ * floating point on the ABI is f64, as in the reference (vec3.rs:11-15,
+ * color.rs:16-20).  Every function returns RT_OK (0) or a negative RT_ERR_*
+ * code; the message for the last error on the calling thread is available
+ * from rt_hip_last_error().
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status */
+#define RT_OK 0
+#define RT_ERR_BAD_ARG (-1)     /* NULL pointer, inconsistent sizes, bad index */
+#define RT_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define RT_ERR_OOM (-3)         /* device or host allocation failed */
+#define RT_ERR_UNSUPPORTED (-4) /* valid input the device path cannot run */
+
+/* ------------------------------------------------------------ enum tags */
+/* Element enum order, elements/mod.rs:59-63 */
+#define RT_PRIM_SPHERE 0
+#define RT_PRIM_QUAD 1
+#define RT_PRIM_TRIANGLE 2
+
+/* Material enum order, materials/mod.rs:23-28 */
+#define RT_MAT_LAMBERTIAN 0
+#define RT_MAT_METAL 1
+#define RT_MAT_DIELECTRIC 2
+#define RT_MAT_DIFFUSE_LIGHT 3
+
+/* Random-number modes.
+ * RT_RNG_REF : one xoshiro256++ per image row seeded with the row index and
+ *              consumed sequentially across the row (integrator.rs:263).
+ *              Inherently serial per row: CPU oracle only.
+ * RT_RNG_CTR : one counter-based stream per path keyed by
+ *              (pixel, batch, sample); the order of draws inside a path is
+ *              the reference's.  Identical on the CPU oracle and the GPU, and
+ *              independent of tiling / GPU count. */
+#define RT_RNG_REF 0
+#define RT_RNG_CTR 1
+
+/* RtConfig.flags (device path; none of them changes a pixel value).
+ * RT_FLAG_TIME_KERNELS    bracket every kernel launch with events and report
+ *                         the device durations in RtStats.
+ * RT_FLAG_COUNT_VISITS    count BVH node visits / leaf tests in RtStats.
+ * RT_FLAG_EARLY_TERMINATE stop a path as soon as its contribution is exactly
+ *                         zero (scattering pdf 0, NaN pdf: integrator.rs:413-419
+ *                         zeroes those anyway).  The reference still traces
+ *                         such sub-paths, so ray counts drop below its count. */
+#define RT_FLAG_TIME_KERNELS 1
+#define RT_FLAG_COUNT_VISITS 2
+#define RT_FLAG_EARLY_TERMINATE 4
+
+/* RtImage.memory */
+#define RT_MEM_HOST 0
+#define RT_MEM_DEVICE 1
+
+/* ------------------------------------------------------------------ PODs */
+typedef struct RtVec3 {
+  double x, y, z;
+} RtVec3;
+
+/* The Camera fields get_prime_ray reads (camera.rs:16-30, 95-120). */
+typedef struct RtCamera {
+  RtVec3 camera_center;
+  RtVec3 pixel00_loc;
+  RtVec3 pixel_delta_u;
+  RtVec3 pixel_delta_v;
+  RtVec3 defocus_disk_u;
+  RtVec3 defocus_disk_v;
+  double defocus_angle;
+} RtCamera;
+
+/* Material (materials/mod.rs:23-28): albedo for Lambertian / Metal /
+ * DiffuseLight; param = fuzz (Metal, metal.rs:10-13) or index_of_refraction
+ * (Dielectric, dielectric.rs:9-13). */
+typedef struct RtMaterial {
+  int32_t kind;
+  int32_t reserved;
+  double albedo[3];
+  double param;
+} RtMaterial;
+
+/* Triangle with the fields Triangle::new precomputes (triangle.rs:24-33,
+ * 55-70).  The bounding box is not needed: boxes live in the nodes. */
+typedef struct RtTriangle {
+  RtVec3 v0, v0v1, v0v2, normal;
+  int32_t material;
+  int32_t reserved;
+} RtTriangle;
+
+/* Quad with the fields Quad::new precomputes (quad.rs:41-55, 69-89). */
+typedef struct RtQuad {
+  RtVec3 q, u, v, normal, w;
+  double d, area;
+  int32_t material;
+  int32_t attractor; /* 1 iff attractor == Some(true) (quad.rs:102-104) */
+} RtQuad;
+
+/* Sphere (sphere.rs:51-57). */
+typedef struct RtSphere {
+  RtVec3 center;
+  double radius;
+  int32_t material;
+  int32_t attractor;
+} RtSphere;
+
+/* objects[i] of the reference's Vec<Element> (integrator.rs:167-177):
+ * which per-kind array holds it and where.  The element index i is the
+ * "primitive id" reported by rt_hip_primary_hits. */
+typedef struct RtElementRef {
+  int32_t kind;
+  int32_t index;
+} RtElementRef;
+
+/* One BVHNode_SAH in the reference's preorder vector
+ * (bvh_node_sah.rs:102-132, 137-143): either a Leaf{element_index} or a
+ * Node{child_l_index, child_l_aabb, child_r_index, child_r_aabb}.  Only the
+ * min/max corners of each Aabb are read on the hot path (aabb.rs:187-204). */
+typedef struct RtNode {
+  int32_t is_leaf;
+  int32_t element_index; /* leaf only */
+  int32_t child_l_index; /* node only */
+  int32_t child_r_index; /* node only */
+  double child_l_min[3], child_l_max[3];
+  double child_r_min[3], child_r_max[3];
+} RtNode;
+
+typedef struct RtScene {
+  RtCamera camera;
+  int32_t n_nodes;
+  int32_t n_elements;
+  int32_t n_triangles;
+  int32_t n_quads;
+  int32_t n_spheres;
+  int32_t n_materials;
+  int32_t n_attractors;
+  int32_t reserved;
+  const RtNode *nodes;          /* nodes[0] is the root (bvh_node_sah.rs:164) */
+  const RtElementRef *elements; /* Vec<Element> order */
+  const RtTriangle *triangles;
+  const RtQuad *quads;
+  const RtSphere *spheres;
+  const RtMaterial *materials;
+  const int32_t *attractors; /* element indices, objects order (integrator.rs:192) */
+} RtScene;
+
+/* Config fields render_line reads (config.rs:8-20, integrator.rs:253-339)
+ * plus what the reference fixes in RenderIntegrator::new (filter B, C:
+ * integrator.rs:47-52) and the row shard this call renders. */
+typedef struct RtConfig {
+  int32_t img_width;  /* config.img_width as usize */
+  int32_t img_height; /* config.img_height as usize */
+  int32_t sample_batch_size;
+  int32_t max_sample_batches;
+  int32_t min_sample_batches;
+  int32_t max_depth;
+  double pixel_radius;
+  double gamma_correction;
+  double filter_b; /* 1/3 in the reference */
+  double filter_c; /* 1/3 in the reference */
+  int32_t rng_mode; /* RT_RNG_REF | RT_RNG_CTR */
+  int32_t flags;    /* RT_FLAG_* bits, 0 for the reference's behaviour */
+  uint64_t seed; /* extra key for RT_RNG_CTR; ignored by RT_RNG_REF */
+  /* Row shard: this call renders image rows y = row_first + k*row_stride
+   * (k = 0,1,...) with y < img_height.  (0,1) is the whole image.  Output
+   * buffers hold only those rows, k-th owned row at offset k*img_width. */
+  int32_t row_first;
+  int32_t row_stride;
+} RtConfig;
+
+/* Output buffers, caller-allocated, library-filled.  n_rows = number of rows
+ * in the shard.  Any pointer may be NULL (that output is skipped) except
+ * `pixels`.  With memory == RT_MEM_DEVICE the pointers are device pointers
+ * on the device the scene was uploaded to. */
+typedef struct RtImage {
+  double *pixels;        /* n_rows*width*3: clamped, gamma-encoded (integrator.rs:331) */
+  double *sample_pixels; /* n_rows*width*3: heat-map (factor,1-factor,0) (integrator.rs:333-337) */
+  double *linear;        /* n_rows*width*3: stats.mean() before clamp/gamma (not in the reference) */
+  uint32_t *samples;     /* n_rows*width: actual_samples per pixel (integrator.rs:315) */
+  int32_t memory;        /* RT_MEM_HOST | RT_MEM_DEVICE */
+  int32_t reserved;
+} RtImage;
+
+#define RT_MAX_DEPTH_STATS 16
+
+/* Counters the reference lacks (it has no ray counter).  A "ray" is one BVH
+ * closest-hit query, i.e. one call of BVH_SAH::hit at integrator.rs:359. */
+typedef struct RtStats {
+  uint64_t rays;                           /* BVH closest-hit queries */
+  uint64_t rays_by_depth[RT_MAX_DEPTH_STATS]; /* index = bounce number, 0 = primary */
+  uint64_t samples;                        /* primary samples (paths) */
+  uint64_t batches;                        /* batch rounds executed */
+  uint64_t node_visits;  /* internal nodes entered (oracle; device if instrumented) */
+  uint64_t box_tests;    /* Aabb::hit calls */
+  uint64_t leaf_tests;   /* Element::hit calls from BVH leaves */
+  double wall_ms;        /* call wall time, scene already resident */
+  double trace_kernel_ms;    /* sum of device durations of the trace/shade kernel */
+  uint64_t trace_launches;   /* number of launches of that kernel */
+  double other_kernel_ms;    /* generate + accumulate/z-test + finalize kernels */
+} RtStats;
+
+typedef struct RtSceneHandle RtSceneHandle;
+
+/* ------------------------------------------------------------- functions */
+
+/* Message for the last error on this thread ("" if none). */
+const char *rt_hip_last_error(void);
+
+/* Number of visible HIP devices, or a negative RT_ERR_* code. */
+int rt_hip_device_count(void);
+
+/* Copy a scene to `device` (validates every index first).  The host arrays
+ * are not referenced after return.  Criterion-style repeated renders
+ * (benches/default_benchmark.rs:119-120) reuse the handle. */
+int rt_hip_scene_upload(const RtScene *scene, int device, RtSceneHandle **out);
+int rt_hip_scene_free(RtSceneHandle *handle);
+
+/* Replaces the Rayon loop integrator.rs:226-243 for the rows of the shard:
+ * fills out->pixels / sample_pixels exactly as render_line does for each of
+ * those rows (RT_RNG_CTR streams).  Blocking; one call in flight per handle. */
+int rt_hip_render_resident(RtSceneHandle *handle, const RtConfig *cfg, RtImage *out,
+                           RtStats *stats);
+
+/* One-shot convenience: upload to device 0, render, free. */
+int rt_hip_render(const RtScene *scene, const RtConfig *cfg, RtImage *out, RtStats *stats);
+
+/* Parity gate: for every pixel of the shard and every sample i of batch 0,
+ * the element index hit by the primary ray (camera.rs:95-120 ->
+ * bvh_node_sah.rs:162-165) or -1, and its t (0 if no hit).  Arrays hold
+ * n_rows*width*sample_batch_size entries, sample index fastest.  Host
+ * pointers. */
+int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *prim_id, double *t);
+
+/* Closest-hit queries for caller-supplied rays (origin, un-normalised
+ * direction; Ray::new normalises, ray.rs:35-48) with the interval
+ * (0.0001, f64::MAX) of integrator.rs:359.  Host pointers, n rays. */
+int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins,
+                      const double *directions, int32_t *prim_id, double *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,409 @@
+// Scene ingestion on the host: Config / camera / element expansion.
+// Restates the load-time half of the reference (config.rs, camera.rs:35-91,
+// elements/{triangle,quad,sphere,cube,obj}.rs, linalg/mat4.rs transforms) so
+// that the POD scene handed to rt_hip.h is the one the Rust host would build.
+#include "scene.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace rt {
+
+// ------------------------------------------------------------------ Aabb
+static Vec3 centroid_of(Vec3 mn, Vec3 mx) {  // aabb.rs:214-220
+  return {mn.x + (mx.x - mn.x) / 2., mn.y + (mx.y - mn.y) / 2., mn.z + (mx.z - mn.z) / 2.};
+}
+
+Aabb Aabb::from_points(Vec3 p, Vec3 q) {
+  Aabb b;
+  b.min = {std::fmin(q.x, p.x), std::fmin(q.y, p.y), std::fmin(q.z, p.z)};
+  b.max = {std::fmax(q.x, p.x), std::fmax(q.y, p.y), std::fmax(q.z, p.z)};
+  b.centroid = centroid_of(b.min, b.max);
+  return b;
+}
+
+Aabb Aabb::merge(const Aabb &a, const Aabb &b) {  // interval.rs:15-20 per axis
+  Aabb r;
+  r.min = vmin(a.min, b.min);
+  r.max = vmax(a.max, b.max);
+  r.centroid = centroid_of(r.min, r.max);
+  return r;
+}
+
+Aabb Aabb::pad() const {
+  const double delta = 0.0001;
+  Aabb r;
+  double mn[3] = {min.x, min.y, min.z}, mx[3] = {max.x, max.y, max.z};
+  for (int a = 0; a < 3; a++) {
+    if (!(mx[a] - mn[a] >= delta)) {  // interval.rs:26-29: expand by delta/2 each side
+      double padding = delta / 2.0;
+      mn[a] = mn[a] - padding;
+      mx[a] = mx[a] + padding;
+    }
+  }
+  r.min = {mn[0], mn[1], mn[2]};
+  r.max = {mx[0], mx[1], mx[2]};
+  r.centroid = centroid_of(r.min, r.max);
+  return r;
+}
+
+double Aabb::area() const {
+  return (max.x - min.x) * (max.y - min.y) + (max.y - min.y) * (max.z - min.z) + (max.z - min.z) * (max.x - min.x);
+}
+
+int Aabb::largest_axis() const {
+  Vec3 size = max - min;
+  if (size.x > size.y && size.x > size.z) return 0;
+  if (size.y > size.z) return 1;
+  return 2;
+}
+
+// ---------------------------------------------------------------- Config
+static Vec3 vec3_from_json(const Json &j) { return {j.at("x").as_number(), j.at("y").as_number(), j.at("z").as_number()}; }
+
+static int64_t usize_from_json(const Json &j, const char *name) {
+  double d = j.at(name).as_number();
+  if (!(d >= 0) || d != std::floor(d)) throw std::runtime_error(std::string("field `") + name + "` must be a non-negative integer");
+  return (int64_t)d;
+}
+
+Config Config::from_json(const Json &j) {
+  Config c;
+  c.img_width = j.at("img_width").as_number();
+  c.img_height = j.at("img_height").as_number();
+  c.sample_batch_size = usize_from_json(j, "sample_batch_size");
+  c.max_sample_batches = usize_from_json(j, "max_sample_batches");
+  c.min_sample_batches = usize_from_json(j, "min_sample_batches");
+  c.max_depth = usize_from_json(j, "max_depth");
+  const Json &sky = j.at("sky_color");
+  c.sky_color[0] = sky.at("r").as_number();
+  c.sky_color[1] = sky.at("g").as_number();
+  c.sky_color[2] = sky.at("b").as_number();
+  c.pixel_radius = j.at("pixel_radius").as_number();
+  c.gamma_correction = j.at("gamma_correction").as_number();
+  const Json *sm = j.find("bvh_split_method");  // Option<BVHSplitMethod>
+  if (sm && !sm->is_null()) {
+    const std::string &s = sm->as_string();
+    c.has_split_method = true;
+    if (s == "SAH") c.split_method = SplitMethod::SAH;
+    else if (s == "Mid") c.split_method = SplitMethod::Mid;
+    else throw std::runtime_error("unknown variant `" + s + "`, expected `Mid` or `SAH`");
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------- Camera
+RtCamera make_camera(const Config &cfg, const JsonCamera &jc) {
+  const double PI = 3.14159265358979323846;
+  Vec3 relative_up{0.0, 1.0, 0.0};
+  double ratio = cfg.img_width / cfg.img_height;
+  double theta = jc.fov_vertical * (PI / 180.0);  // f64::to_radians
+  double h = std::tan(theta / 2.0);
+  double vv = 2.0 * h * jc.focus_dist;
+  double vu = vv * ratio;
+  Vec3 w = normalized(jc.center - jc.look_at);
+  Vec3 u = normalized(cross(relative_up, w));
+  Vec3 v = cross(w, u);
+  Vec3 viewport_u = u * vu;
+  Vec3 viewport_v = v * -1.0 * vv;
+  Vec3 pixel_delta_u = viewport_u / cfg.img_width;
+  Vec3 pixel_delta_v = viewport_v / (cfg.img_width / ratio);
+  Vec3 viewport_upper_left = jc.center - (w * jc.focus_dist) - viewport_u / 2.0 - viewport_v / 2.0;
+  Vec3 pixel00_loc = viewport_upper_left + (pixel_delta_u + pixel_delta_v) * 0.5;
+  double defocus_radius = jc.focus_dist * std::tan((jc.defocus_angle / 2.0) * (PI / 180.0));
+  RtCamera c{};
+  c.camera_center = abi(jc.center);
+  c.pixel00_loc = abi(pixel00_loc);
+  c.pixel_delta_u = abi(pixel_delta_u);
+  c.pixel_delta_v = abi(pixel_delta_v);
+  c.defocus_disk_u = abi(u * defocus_radius);
+  c.defocus_disk_v = abi(v * defocus_radius);
+  c.defocus_angle = jc.defocus_angle;
+  return c;
+}
+
+// ------------------------------------------------------- element builders
+void SceneData::add_triangle(Vec3 v0, Vec3 v1, Vec3 v2, int material) {
+  Vec3 v0v1 = v1 - v0, v0v2 = v2 - v0;
+  Vec3 normal = normalized(cross(v0v1, v0v2));
+  RtTriangle t{};
+  t.v0 = abi(v0);
+  t.v0v1 = abi(v0v1);
+  t.v0v2 = abi(v0v2);
+  t.normal = abi(normal);
+  t.material = material;
+  Element e;
+  e.kind = RT_PRIM_TRIANGLE;
+  e.index = (int)triangles.size();
+  e.bbox = Aabb::from_points(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2))).pad();
+  triangles.push_back(t);
+  elements.push_back(e);
+}
+
+void SceneData::add_quad(Vec3 q, Vec3 u, Vec3 v, int material, bool attractor) {
+  Vec3 n = cross(u, v);
+  Vec3 normal = normalized(n);
+  RtQuad r{};
+  r.q = abi(q);
+  r.u = abi(u);
+  r.v = abi(v);
+  r.normal = abi(normal);
+  r.d = dot(normal, q);
+  r.w = abi(n / dot(n, n));
+  r.area = length(n);
+  r.material = material;
+  r.attractor = attractor ? 1 : 0;
+  Element e;
+  e.kind = RT_PRIM_QUAD;
+  e.index = (int)quads.size();
+  e.bbox = Aabb::from_points(q, q + u + v).pad();  // exact only for axis-aligned quads, as in the reference
+  quads.push_back(r);
+  elements.push_back(e);
+}
+
+void SceneData::add_sphere(Vec3 center, double radius, int material, bool attractor) {
+  RtSphere s{};
+  s.center = abi(center);
+  s.radius = radius;
+  s.material = material;
+  s.attractor = attractor ? 1 : 0;
+  Vec3 rvec{radius, radius, radius};
+  Element e;
+  e.kind = RT_PRIM_SPHERE;
+  e.index = (int)spheres.size();
+  e.bbox = Aabb::from_points(center - rvec, center + rvec);
+  spheres.push_back(s);
+  elements.push_back(e);
+}
+
+// --------------------------------------------------------------- Mat4
+// linalg/mat4.rs:28-99 (constructors) and 281-304 (Mat4 * Vec4 with w = 1;
+// only x,y,z of the product are kept, vec4.rs:28-30).
+struct Mat4 {
+  double m[4][4];
+  Vec3 apply(Vec3 v) const {
+    const double w = 1.0;
+    return {m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z + m[0][3] * w,
+            m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z + m[1][3] * w,
+            m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z + m[2][3] * w};
+  }
+};
+static Mat4 mat_translate(double dx, double dy, double dz) {  // the reference calls this "transpose"
+  return Mat4{{{1., 0., 0., dx}, {0., 1., 0., dy}, {0., 0., 1., dz}, {0., 0., 0., 1.}}};
+}
+static Mat4 mat_scale(double sx, double sy, double sz) {
+  return Mat4{{{sx, 0., 0., 0.}, {0., sy, 0., 0.}, {0., 0., sz, 0.}, {0., 0., 0., 0.}}};
+}
+static Mat4 mat_rotate_x(double t) {
+  return Mat4{{{1., 0., 0., 0.}, {0., std::cos(t), std::sin(t), 0.}, {0., -std::sin(t), std::cos(t), 0.}, {0., 0., 0., 1.}}};
+}
+static Mat4 mat_rotate_y(double t) {
+  return Mat4{{{std::cos(t), 0., -std::sin(t), 0.}, {0., 1., 0., 0.}, {std::sin(t), 0., std::cos(t), 0.}, {0., 0., 0., 1.}}};
+}
+static Mat4 mat_rotate_z(double t) {
+  return Mat4{{{std::cos(t), -std::sin(t), 0., 0.}, {std::sin(t), std::cos(t), 0., 0.}, {0., 0., 1., 0.}, {0., 0., 0., 1.}}};
+}
+static void apply_all(const Mat4 &m, std::vector<Vec3> &vs) {
+  for (auto &v : vs) v = m.apply(v);
+}
+
+struct Transform {  // elements/mod.rs:78-97
+  bool has_translate = false, has_rotate = false, has_scale = false;
+  Vec3 translate, rotate, scale;
+};
+static Transform transform_from_json(const Json &j) {
+  Transform t;
+  if (const Json *p = j.find("transpose"); p && !p->is_null()) {
+    t.has_translate = true;
+    t.translate = vec3_from_json(*p);
+  }
+  if (const Json *p = j.find("rotate"); p && !p->is_null()) {
+    t.has_rotate = true;
+    t.rotate = {p->at("theta_x").as_number(), p->at("theta_y").as_number(), p->at("theta_z").as_number()};
+  }
+  if (const Json *p = j.find("scale"); p && !p->is_null()) {
+    t.has_scale = true;
+    t.scale = vec3_from_json(*p);
+  }
+  return t;
+}
+
+// materials/mod.rs:22-28 (externally tagged enum)
+static int material_from_json(const Json &j, SceneData &out) {
+  if (j.kind != Json::Object || j.object.size() != 1) throw std::runtime_error("material: expected a single-variant object");
+  const std::string &tag = j.object[0].first;
+  const Json &body = j.object[0].second;
+  RtMaterial m{};
+  auto albedo = [&](const Json &b) {
+    const Json &a = b.at("albedo");
+    m.albedo[0] = a.at("r").as_number();
+    m.albedo[1] = a.at("g").as_number();
+    m.albedo[2] = a.at("b").as_number();
+  };
+  if (tag == "Lambertian") {
+    m.kind = RT_MAT_LAMBERTIAN;
+    albedo(body);
+  } else if (tag == "Metal") {
+    m.kind = RT_MAT_METAL;
+    albedo(body);
+    m.param = body.at("fuzz").as_number();
+  } else if (tag == "Dielectric") {
+    m.kind = RT_MAT_DIELECTRIC;
+    m.param = body.at("index_of_refraction").as_number();
+  } else if (tag == "DiffuseLight") {
+    m.kind = RT_MAT_DIFFUSE_LIGHT;
+    albedo(body);
+  } else {
+    throw std::runtime_error("unknown material variant `" + tag + "`");
+  }
+  out.materials.push_back(m);
+  return (int)out.materials.size() - 1;
+}
+
+static bool option_true(const Json &j, const char *name) {  // Option<bool> == Some(true)
+  const Json *p = j.find(name);
+  return p && p->kind == Json::Bool && p->boolean;
+}
+
+// elements/cube.rs:26-144
+static void add_box(const Json &j, SceneData &out) {
+  Vec3 a = vec3_from_json(j.at("a")), b = vec3_from_json(j.at("b"));
+  int material = material_from_json(j.at("material"), out);
+  Transform tf = transform_from_json(j);
+  Vec3 mn = vmin(a, b), mx = vmax(a, b);
+  double dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+  std::vector<Vec3> v = {{1., -1., 1.},  {1., -1., -1.},  {1., 1., -1.},  {1., 1., 1.},
+                         {-1., -1., 1.}, {-1., -1., -1.}, {-1., 1., -1.}, {-1., 1., 1.}};
+  static const int tris[12][3] = {{1, 5, 6}, {1, 6, 2}, {5, 7, 6}, {5, 4, 7}, {0, 2, 3}, {0, 1, 2},
+                                  {2, 7, 3}, {2, 6, 7}, {0, 7, 4}, {0, 3, 7}, {4, 5, 1}, {1, 0, 4}};
+  apply_all(mat_scale(dx / 2., dy / 2., dz / 2.), v);
+  if (tf.has_scale) apply_all(mat_scale(tf.scale.x, tf.scale.y, tf.scale.z), v);
+  if (tf.has_rotate) {
+    apply_all(mat_rotate_x(tf.rotate.x), v);
+    apply_all(mat_rotate_y(tf.rotate.y), v);
+    apply_all(mat_rotate_z(tf.rotate.z), v);
+  }
+  apply_all(mat_translate(mn.x + dx / 2.0, mn.y + dy / 2.0, mn.z + dz / 2.0), v);
+  if (tf.has_translate) apply_all(mat_translate(tf.translate.x, tf.translate.y, tf.translate.z), v);
+  for (const auto &t : tris) out.add_triangle(v[t[0]], v[t[1]], v[t[2]], material);
+}
+
+// elements/obj.rs:27-103.  The reference parses with the wavefront_obj crate
+// (10.0.0, source not in the reference tree): per-object vertex lists with
+// object-local 0-based indices, polygons fan-triangulated, only triangles
+// consumed.  Restated here for `v`, `f` (with v/vt/vn forms), `o`.
+static void add_obj(const Json &j, const std::string &base_dir, SceneData &out) {
+  std::string path = j.at("filepath").as_string();
+  if (!base_dir.empty() && !path.empty() && path[0] != '/') path = base_dir + "/" + path;
+  int material = material_from_json(j.at("material"), out);
+  Transform tf = transform_from_json(j);
+
+  std::ifstream f(path);
+  if (!f) throw std::runtime_error("cannot open obj file `" + path + "`");
+
+  struct Obj {
+    std::vector<Vec3> vertices;
+    std::vector<int64_t> faces;  // triples of object-local indices
+    size_t first_vertex = 0;     // global index of vertices[0]
+  };
+  std::vector<Obj> objects(1);
+  size_t global_vertices = 0;
+  std::string line;
+  std::vector<int64_t> poly;
+  while (std::getline(f, line)) {
+    const char *p = line.c_str();
+    while (*p == ' ' || *p == '\t') p++;
+    if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+      char *end;
+      double x = std::strtod(p + 1, &end);
+      double y = std::strtod(end, &end);
+      double z = std::strtod(end, &end);
+      objects.back().vertices.push_back({x, y, z});
+      global_vertices++;
+    } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+      poly.clear();
+      const char *q = p + 1;
+      while (*q) {
+        while (*q == ' ' || *q == '\t' || *q == '\r') q++;
+        if (!*q) break;
+        char *end;
+        long long idx = std::strtoll(q, &end, 10);
+        if (end == q) throw std::runtime_error("obj: bad face index in `" + path + "`");
+        if (idx < 0) idx = (long long)global_vertices + idx + 1;  // relative index
+        poly.push_back((int64_t)idx - 1 - (int64_t)objects.back().first_vertex);
+        q = end;
+        while (*q && *q != ' ' && *q != '\t' && *q != '\r') q++;  // skip /vt/vn
+      }
+      for (size_t k = 1; k + 1 < poly.size(); k++) {
+        objects.back().faces.push_back(poly[0]);
+        objects.back().faces.push_back(poly[k]);
+        objects.back().faces.push_back(poly[k + 1]);
+      }
+    } else if (p[0] == 'o' && (p[1] == ' ' || p[1] == '\t')) {
+      if (!objects.back().vertices.empty() || !objects.back().faces.empty()) {
+        objects.emplace_back();
+        objects.back().first_vertex = global_vertices;
+      }
+    }
+  }
+
+  for (auto &o : objects) {
+    std::vector<Vec3> &v = o.vertices;
+    if (tf.has_scale) apply_all(mat_scale(tf.scale.x, tf.scale.y, tf.scale.z), v);
+    if (tf.has_rotate) {
+      apply_all(mat_rotate_x(tf.rotate.x), v);
+      apply_all(mat_rotate_y(tf.rotate.y), v);
+      apply_all(mat_rotate_z(tf.rotate.z), v);
+    }
+    if (tf.has_translate) apply_all(mat_translate(tf.translate.x, tf.translate.y, tf.translate.z), v);
+    for (size_t k = 0; k + 2 < o.faces.size(); k += 3) {
+      int64_t a = o.faces[k], b = o.faces[k + 1], c = o.faces[k + 2];
+      if (a < 0 || b < 0 || c < 0 || a >= (int64_t)v.size() || b >= (int64_t)v.size() || c >= (int64_t)v.size())
+        throw std::runtime_error("obj: face index out of range in `" + path + "`");
+      out.add_triangle(v[a], v[b], v[c], material);
+    }
+  }
+}
+
+void expand_elements(const Json &scene, const std::string &base_dir, SceneData &out) {
+  const Json &elements = scene.at("elements");
+  if (elements.kind != Json::Array) throw std::runtime_error("`elements` must be an array");
+  for (const Json &je : elements.array) {
+    if (je.kind != Json::Object || je.object.size() != 1) throw std::runtime_error("element: expected a single-variant object");
+    const std::string &tag = je.object[0].first;
+    const Json &body = je.object[0].second;
+    if (tag == "JSONQuad") {  // quad.rs:26-37
+      int material = material_from_json(body.at("material"), out);
+      out.add_quad(vec3_from_json(body.at("q")), vec3_from_json(body.at("u")), vec3_from_json(body.at("v")), material,
+                   option_true(body, "attractor"));
+    } else if (tag == "JSONSphere") {  // sphere.rs:29-47
+      int material = material_from_json(body.at("material"), out);
+      Vec3 center = vec3_from_json(body.at("center"));
+      Transform tf = transform_from_json(body);
+      if (tf.has_translate) center = mat_translate(tf.translate.x, tf.translate.y, tf.translate.z).apply(center);
+      out.add_sphere(center, body.at("radius").as_number(), material, option_true(body, "attractor"));
+    } else if (tag == "JSONTriangle") {  // triangle.rs:35-41
+      int material = material_from_json(body.at("material"), out);
+      out.add_triangle(vec3_from_json(body.at("v0")), vec3_from_json(body.at("v1")), vec3_from_json(body.at("v2")), material);
+    } else if (tag == "JSONBox") {
+      add_box(body, out);
+    } else if (tag == "JSONObj") {
+      add_obj(body, base_dir, out);
+    } else {
+      throw std::runtime_error("unknown element variant `" + tag + "`");
+    }
+  }
+  // integrator.rs:192 / elements/mod.rs:68-75: spheres and quads flagged Some(true)
+  for (size_t i = 0; i < out.elements.size(); i++) {
+    const Element &e = out.elements[i];
+    bool a = (e.kind == RT_PRIM_SPHERE && out.spheres[e.index].attractor) || (e.kind == RT_PRIM_QUAD && out.quads[e.index].attractor);
+    if (a) out.attractors.push_back((int32_t)i);
+  }
+  out.element_refs.resize(out.elements.size());
+  for (size_t i = 0; i < out.elements.size(); i++) out.element_refs[i] = RtElementRef{out.elements[i].kind, out.elements[i].index};
+}
+
+}  // namespace rt

@@ -1,0 +1,400 @@
+// Device-side math, sampling and intersection routines of the MI355X path
+// tracer (gfx950 only).  All radiometric and geometric arithmetic is f64 and
+// keeps the reference's operation order (this translation unit is compiled
+// with -ffp-contract=off: the Rust reference never fuses a multiply-add), so
+// that a primitive test returns the same t bits as the reference's.  Only the
+// BVH child boxes are stored in f32, rounded outward.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd {
+
+constexpr double kEpsilon = 2.220446049250313e-16;  // f64::EPSILON
+constexpr double kPi = 3.14159265358979323846;      // std::f64::consts::PI
+constexpr double kF64Max = 1.7976931348623157e308;
+constexpr double kTMin = 0.0001;  // integrator.rs:359
+
+// ------------------------------------------------------------ child refs
+// A child reference / stack entry packs: bit31 leaf, bits30-29 primitive kind
+// (RT_PRIM_*), bit28 "box test passed" (stack entries only), bits27-0 index
+// (internal-node index, or slot in the per-kind primitive array).
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefFlag = 0x10000000u;
+constexpr uint32_t kRefIndexMask = 0x0fffffffu;
+constexpr uint32_t kRefNone = 0xffffffffu;
+constexpr int kRefKindShift = 29;
+constexpr int kMaxStackDepth = 64;
+
+// 64-byte internal node: both child boxes (f32, rounded outward) + child refs.
+struct __attribute__((aligned(64))) DevNode {
+  float lmin[3], lmax[3], rmin[3], rmax[3];
+  uint32_t left, right;
+  uint32_t pad[2];
+};
+static_assert(sizeof(DevNode) == 64, "node must be one 64-byte record");
+
+// 80-byte triangle record read by the leaf test (triangle.rs:76-117).
+struct __attribute__((aligned(16))) DevTriangle {
+  double v0[3], e1[3], e2[3];
+  uint32_t element, material;
+};
+static_assert(sizeof(DevTriangle) == 80, "triangle record");
+
+struct DevQuad {
+  double q[3], u[3], v[3], normal[3], w[3];
+  double d, area;
+  uint32_t element, material;
+};
+struct DevSphere {
+  double center[3];
+  double radius;
+  uint32_t element, material;
+};
+struct DevMaterial {
+  double albedo[3];
+  double param;
+  int32_t kind;
+  int32_t pad;
+};
+
+struct DevScene {
+  const DevNode *nodes;
+  const DevTriangle *triangles;
+  const double *tri_normals;  // 3 per triangle, Triangle::new's normal
+  const DevQuad *quads;
+  const DevSphere *spheres;
+  const DevMaterial *materials;
+  const uint32_t *attractors;  // leaf refs (kind + index)
+  int32_t n_attractors;
+  uint32_t root;        // ref of nodes[0] of the reference array
+  int32_t stack_depth;  // LDS stack entries per lane
+  RtCamera camera;
+};
+
+// ----------------------------------------------------------------- vec3
+struct d3 {
+  double x, y, z;
+};
+RT_DEV d3 D3(double x, double y, double z) { return d3{x, y, z}; }
+RT_DEV d3 ld3(const double *p) { return d3{p[0], p[1], p[2]}; }
+RT_DEV d3 ld3(const RtVec3 &p) { return d3{p.x, p.y, p.z}; }
+RT_DEV d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV d3 operator*(d3 a, double q) { return {a.x * q, a.y * q, a.z * q}; }
+RT_DEV d3 operator*(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV d3 operator/(d3 a, double q) { return {a.x / q, a.y / q, a.z / q}; }
+RT_DEV d3 neg(d3 a) { return {-a.x, -a.y, -a.z}; }
+RT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV d3 cross(d3 a, d3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT_DEV double length_squared(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_DEV double length(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // vec3.rs:116-128
+RT_DEV d3 normalized(d3 a) {                                                    // vec3.rs:163-166
+  double l = length(a);
+  return {a.x / l, a.y / l, a.z / l};
+}
+RT_DEV bool has_nan(d3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
+
+// ------------------------------------------------------------------ RNG
+// One SplitMix64 stream per path; identical to the CPU oracle's RT_RNG_CTR
+// mode.  The conversions are rand 0.8.5's (gen_range, Standard f64, index).
+RT_DEV uint64_t splitmix64_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+RT_DEV uint64_t rng_seed_path(uint64_t pixel_index, uint64_t batch, uint64_t sample, uint64_t seed) {
+  uint64_t k = splitmix64_mix(pixel_index + 0x9e3779b97f4a7c15ULL);
+  k = splitmix64_mix(k ^ (batch * 0xd1342543de82ef95ULL + 0x632be59bd9b4e019ULL));
+  k = splitmix64_mix(k ^ (sample * 0xaf251af3b0f025b5ULL + 0x9e3779b97f4a7c15ULL));
+  return splitmix64_mix(k ^ seed);
+}
+RT_DEV uint64_t rng_next_u64(uint64_t &s) {
+  s += 0x9e3779b97f4a7c15ULL;
+  return splitmix64_mix(s);
+}
+RT_DEV double rng_gen_range(uint64_t &s, double low, double high) {
+  double scale = high - low;
+  for (;;) {
+    uint64_t bits = (rng_next_u64(s) >> 12) | 0x3ff0000000000000ULL;
+    double value0_1 = __longlong_as_double((long long)bits) - 1.0;
+    double res = value0_1 * scale + low;
+    if (res < high) return res;
+  }
+}
+RT_DEV double rng_gen_f64(uint64_t &s) { return (double)(rng_next_u64(s) >> 11) * (1.0 / 9007199254740992.0); }
+RT_DEV uint32_t rng_gen_index(uint64_t &s, uint32_t n) {
+  uint32_t zone = (n << __clz((int)n)) - 1u;
+  for (;;) {
+    uint32_t v = (uint32_t)(rng_next_u64(s) >> 32);
+    uint64_t m = (uint64_t)v * (uint64_t)n;
+    if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+  }
+}
+RT_DEV d3 random_unit_vector(uint64_t &s) {  // rand_distr UnitSphere, vec3.rs:35-38
+  for (;;) {
+    double x1 = rng_gen_range(s, -1.0, 1.0);
+    double x2 = rng_gen_range(s, -1.0, 1.0);
+    double sum = x1 * x1 + x2 * x2;
+    if (sum >= 1.0) continue;
+    double factor = 2.0 * sqrt(1.0 - sum);
+    return {x1 * factor, x2 * factor, 1.0 - 2.0 * sum};
+  }
+}
+RT_DEV d3 random_in_unit_disk(uint64_t &s) {  // vec3.rs:41-48
+  for (;;) {
+    double a = rng_gen_range(s, -1.0, 1.0);
+    double b = rng_gen_range(s, -1.0, 1.0);
+    if (a * a + b * b + 0.0 * 0.0 < 1.0) return {a, b, 0.0};
+  }
+}
+RT_DEV d3 random_cosine_direction(uint64_t &s) {  // vec3.rs:69-79
+  double r1 = rng_gen_range(s, 0.0, 1.0);
+  double r2 = rng_gen_range(s, 0.0, 1.0);
+  double phi = 2. * kPi * r1;
+  double sn, cs;
+  sincos(phi, &sn, &cs);
+  double sq = sqrt(r2);
+  return {cs * sq, sn * sq, sqrt(1. - r2)};
+}
+
+// ---------------------------------------------------------------- Sobol
+// Owen-scrambled, index-shuffled Sobol (Burley 2020), dims 0 and 1; the same
+// restatement of sobol_burley::sample as the CPU oracle's.
+RT_DEV uint32_t hash_u32(uint32_t n) {
+  n ^= 0xe6fe3beb;
+  n ^= n >> 16;
+  n *= 0x7feb352d;
+  n ^= n >> 15;
+  n *= 0x846ca68b;
+  n ^= n >> 16;
+  return n;
+}
+RT_DEV uint32_t owen_scramble_rev(uint32_t n, uint32_t key) {
+  n ^= n * 0x3d20adea;
+  n += key;
+  n *= (key >> 16) | 1;
+  n ^= n * 0x05526c56;
+  n ^= n * 0x53a22864;
+  return n;
+}
+RT_DEV float sobol_sample(uint32_t index, uint32_t dim, uint32_t seed) {
+  uint32_t shuffled = __brev(owen_scramble_rev(__brev(index), hash_u32(seed)));
+  uint32_t idx = shuffled & 0xffffu;
+  uint32_t x = 0;
+  if (dim == 0) {
+    x = __brev(idx);
+  } else {
+    uint32_t v = 0x80000000u;
+    for (int k = 0; k < 16; k++) {
+      if (idx & (1u << k)) x ^= v;
+      v ^= v >> 1;
+    }
+  }
+  uint32_t key = hash_u32(seed ^ hash_u32(dim + 1u));
+  x = __brev(owen_scramble_rev(__brev(x), key));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// --------------------------------------------------------------- filter
+RT_DEV double mitchell_1d(double x, double b, double c) {  // filter.rs:45-61
+  double fx = fabs(x) * 2.0;
+  if (fx < 1.0) {
+    return ((12.0 - 9.0 * b - 6.0 * c) * fx * fx * fx + (-18.0 + 12.0 * b + 6.0 * c) * fx * fx + (6.0 - 2.0 * b)) * (1.0 / 6.0);
+  } else if (fx < 2.0) {
+    return ((-b - 6.0 * c) * fx * fx * fx + (6.0 * b + 30.0 * c) * fx * fx + (-12.0 * b - 48.0 * c) * fx + (8.0 * b + 24.0 * c)) *
+           (1.0 / 6.0);
+  }
+  return 0.0;
+}
+
+// ------------------------------------------------------------------ ONB
+struct Onb {
+  d3 u, v, w;
+};
+RT_DEV Onb onb_build_from_w(d3 w) {  // onb.rs:31-45
+  d3 unit_w = normalized(w);
+  d3 a = (fabs(unit_w.x) > 0.9) ? D3(0., 1., 0.) : D3(1.0, 0., 0.);
+  d3 v = normalized(cross(unit_w, a));
+  d3 u = cross(unit_w, v);
+  return {u, v, unit_w};
+}
+RT_DEV d3 onb_local_vec(const Onb &o, d3 vec) { return o.u * vec.x + o.v * vec.y + o.w * vec.z; }  // onb.rs:27-29
+
+// ---------------------------------------------------------------- a ray
+struct Ray {
+  d3 o, d, inv;  // Ray::new, ray.rs:35-48 (d already normalised)
+};
+RT_DEV Ray make_ray_normalized(d3 o, d3 dn) { return {o, dn, D3(1.0 / dn.x, 1.0 / dn.y, 1.0 / dn.z)}; }
+RT_DEV Ray make_ray(d3 o, d3 dir) { return make_ray_normalized(o, normalized(dir)); }
+
+// ----------------------------------------------------- primitive tests
+// triangle.rs:76-117; returns true and t when the hit lies in [tmin, tmax].
+RT_DEV bool triangle_hit(d3 v0, d3 e1, d3 e2, const Ray &r, double tmin, double tmax, double &t_out) {
+  d3 pvec = cross(r.d, e2);
+  double det = dot(e1, pvec);
+  if (det < kEpsilon) return false;
+  double inv_det = 1. / det;
+  d3 tvec = r.o - v0;
+  double u = dot(tvec, pvec) * inv_det;
+  if (!(0.0 <= u && u <= 1.0)) return false;
+  d3 qvec = cross(tvec, e1);
+  double v = dot(r.d, qvec) * inv_det;
+  if (v < 0.0 || u + v > 1.0) return false;
+  double t = dot(e2, qvec) * inv_det;
+  if (!(tmin <= t && t <= tmax)) return false;
+  t_out = t;
+  return true;
+}
+// quad.rs:108-145
+RT_DEV bool quad_hit(const DevQuad &q, const Ray &r, double tmin, double tmax, double &t_out) {
+  d3 normal = ld3(q.normal);
+  double denom = dot(normal, r.d);
+  if (fabs(denom) < kEpsilon) return false;
+  double t = (q.d - dot(normal, r.o)) / denom;
+  if (!(tmin <= t && t <= tmax)) return false;
+  d3 p = (r.o + r.d * t) - ld3(q.q);
+  d3 w = ld3(q.w);
+  double alpha = dot(w, cross(p, ld3(q.v)));
+  double beta = dot(w, cross(ld3(q.u), p));
+  if (!(0.0 <= alpha && alpha <= 1.0) || !(0.0 <= beta && beta <= 1.0)) return false;
+  t_out = t;
+  return true;
+}
+// sphere.rs:94-145 (strict interval; only the numerically smaller root)
+RT_DEV bool sphere_hit(const DevSphere &s, const Ray &r, double tmin, double tmax, double &t_out) {
+  d3 l = r.o - ld3(s.center);
+  double a = dot(r.d, r.d);
+  double b = 2.0 * dot(r.d, l);
+  double c = dot(l, l) - (s.radius * s.radius);
+  double discr = b * b - 4.0 * a * c;
+  if (discr >= 0.0) {
+    double q = (b > 0.0) ? -0.5 * (b + sqrt(discr)) : -0.5 * (b - sqrt(discr));
+    double first_root = q / a;
+    double second_root = c / q;
+    if (first_root < 0.0 && second_root < 0.0) return false;
+    double nearest_root = (first_root < second_root) ? first_root : second_root;
+    if (nearest_root < tmax && nearest_root > tmin) {
+      t_out = nearest_root;
+      return true;
+    }
+  }
+  return false;
+}
+
+// aabb.rs:187-204 on an outward-rounded f32 box: evaluated in f64 with the
+// reference's expression, so on a box whose corners are exactly representable
+// in f32 the decision is the reference's, and otherwise the slightly larger
+// box can only add visits (a superset of the reference's leaves is tested).
+RT_DEV bool slab_hit(const float *bmin, const float *bmax, const Ray &r) {
+  double lo, hi;
+  lo = (double)(r.d.x < 0.0 ? bmax[0] : bmin[0]);
+  hi = (double)(r.d.x < 0.0 ? bmin[0] : bmax[0]);
+  double ray_min = (lo - r.o.x) * r.inv.x;
+  double ray_max = (hi - r.o.x) * r.inv.x;
+  lo = (double)(r.d.y < 0.0 ? bmax[1] : bmin[1]);
+  hi = (double)(r.d.y < 0.0 ? bmin[1] : bmax[1]);
+  double y_min = (lo - r.o.y) * r.inv.y;
+  double y_max = (hi - r.o.y) * r.inv.y;
+  ray_min = fmax(ray_min, y_min);
+  ray_max = fmin(ray_max, y_max);
+  lo = (double)(r.d.z < 0.0 ? bmax[2] : bmin[2]);
+  hi = (double)(r.d.z < 0.0 ? bmin[2] : bmax[2]);
+  double z_min = (lo - r.o.z) * r.inv.z;
+  double z_max = (hi - r.o.z) * r.inv.z;
+  ray_min = fmax(ray_min, z_min);
+  ray_max = fmin(ray_max, z_max);
+  return fmax(ray_min, 0.0) <= ray_max;
+}
+
+// ------------------------------------------------ BVH closest-hit query
+// Restates BVH_SAH::hit (bvh_node_sah.rs:162-253) iteratively.  The
+// reference's recursion is an ordered depth-first walk, left child first,
+// that keeps the best t so far in ray_t.interval_max; a later leaf replaces
+// the current hit when its t lies in [tmin, best] (inclusive for triangles
+// and quads, strict for spheres).  Its one irregularity is kept: after the
+// left subtree of a node returned a hit, the right child is entered WITHOUT
+// testing its box (bvh_node_sah.rs:215-216).  `hitmask` bit s records whether
+// a hit was accepted since the entry at stack position s was pushed.
+//
+// `stack` points at this lane's slot of an LDS array laid out
+// [level][thread]; consecutive levels are `stride` entries apart, so a wave's
+// accesses to one level touch 64 consecutive dwords (no bank conflicts).
+struct Hit {
+  double t;
+  uint32_t ref;  // leaf ref of the primitive hit, kRefNone on a miss
+};
+
+template <bool COUNT>
+RT_DEV Hit bvh_closest_hit(const DevScene &sc, const Ray &r, uint32_t *stack, int stride, uint32_t *n_nodes, uint32_t *n_leaves) {
+  Hit best{kF64Max, kRefNone};
+  uint64_t hitmask = 0;
+  int sp = 0;
+  uint32_t cur = sc.root;
+  for (;;) {
+    bool pop = false;
+    if (!(cur & kRefLeaf)) {
+      const DevNode &n = sc.nodes[cur & kRefIndexMask];
+      // four 16-byte loads
+      const float4 *p = reinterpret_cast<const float4 *>(&n);
+      float4 q0 = p[0], q1 = p[1], q2 = p[2];
+      uint2 kids = *reinterpret_cast<const uint2 *>(&n.left);
+      float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+      float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+      if (COUNT) (*n_nodes)++;
+      bool hl = slab_hit(lmin, lmax, r);
+      bool hr = slab_hit(rmin, rmax, r);
+      if (hl) {
+        stack[sp * stride] = kids.y | (hr ? kRefFlag : 0u);
+        hitmask &= ~(1ull << sp);
+        sp++;
+        cur = kids.x;
+      } else if (hr) {
+        cur = kids.y;
+      } else {
+        pop = true;
+      }
+    } else {
+      uint32_t kind = (cur >> kRefKindShift) & 3u;
+      uint32_t idx = cur & kRefIndexMask;
+      double t;
+      bool ok;
+      if (COUNT) (*n_leaves)++;
+      if (kind == RT_PRIM_TRIANGLE) {
+        const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[idx]);
+        double2 a = p[0], b = p[1], c = p[2], d = p[3];
+        double e2z = reinterpret_cast<const double *>(p)[8];
+        ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(d.x, d.y, e2z), r, kTMin, best.t, t);
+      } else if (kind == RT_PRIM_QUAD) {
+        ok = quad_hit(sc.quads[idx], r, kTMin, best.t, t);
+      } else {
+        ok = sphere_hit(sc.spheres[idx], r, kTMin, best.t, t);
+      }
+      if (ok) {
+        best.t = t;
+        best.ref = cur;
+        hitmask = ~0ull;
+      }
+      pop = true;
+    }
+    if (pop) {
+      for (;;) {
+        if (sp == 0) return best;
+        sp--;
+        uint32_t e = stack[sp * stride];
+        bool left_hit = (hitmask >> sp) & 1ull;
+        if ((e & kRefFlag) || left_hit) {
+          cur = e & ~kRefFlag;
+          break;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rtd

@@ -1,0 +1,184 @@
+"""Python face of the native host: the reference's RenderIntegrator surface
+(/root/reference/src/render/integrator.rs:38-249 -- new_from_json, render,
+save_to_png) on top of librt_host.so / librt_hip.so.
+
+Nothing here computes pixels: every method forwards to the C ABI.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import abi
+
+
+class ResidentScene:
+    """A scene uploaded to one GPU (rt_hip_scene_upload)."""
+
+    def __init__(self, scene_ptr, device=0):
+        self._h = C.c_void_p()
+        abi.check_hip(abi.hip_lib().rt_hip_scene_upload(scene_ptr, int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            abi.hip_lib().rt_hip_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cfg, want_linear=True, want_samples=True, device_out=None):
+        """Render the row shard named by cfg.  Returns (dict of numpy arrays, RtStats).
+
+        With `device_out` (a dict of torch CUDA tensors named pixels / sample_pixels /
+        linear / samples) the kernels write straight into those tensors.
+        """
+        n_rows, w = cfg.n_rows(), cfg.img_width
+        img = abi.RtImage()
+        stats = abi.RtStats()
+        if device_out is not None:
+            img.memory = abi.RT_MEM_DEVICE
+            for name in ("pixels", "sample_pixels", "linear", "samples"):
+                t = device_out.get(name)
+                if t is not None:
+                    setattr(img, name, t.data_ptr())
+            abi.check_hip(abi.hip_lib().rt_hip_render_resident(self._h, C.byref(cfg), C.byref(img), C.byref(stats)))
+            return device_out, stats
+        out = {
+            "pixels": np.empty((n_rows, w, 3), dtype=np.float64),
+            "sample_pixels": np.empty((n_rows, w, 3), dtype=np.float64),
+        }
+        if want_linear:
+            out["linear"] = np.empty((n_rows, w, 3), dtype=np.float64)
+        if want_samples:
+            out["samples"] = np.empty((n_rows, w), dtype=np.uint32)
+        img.memory = abi.RT_MEM_HOST
+        for name, arr in out.items():
+            setattr(img, name, arr.ctypes.data)
+        abi.check_hip(abi.hip_lib().rt_hip_render_resident(self._h, C.byref(cfg), C.byref(img), C.byref(stats)))
+        return out, stats
+
+    def primary_hits(self, cfg):
+        n = cfg.n_rows() * cfg.img_width * cfg.sample_batch_size
+        prim = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float64)
+        abi.check_hip(abi.hip_lib().rt_hip_primary_hits(self._h, C.byref(cfg), prim.ctypes.data, t.ctypes.data))
+        shape = (cfg.n_rows(), cfg.img_width, cfg.sample_batch_size)
+        return prim.reshape(shape), t.reshape(shape)
+
+    def trace_rays(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        assert o.shape == d.shape
+        n = o.shape[0]
+        prim = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float64)
+        abi.check_hip(abi.hip_lib().rt_hip_trace_rays(self._h, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data, t.ctypes.data))
+        return prim, t
+
+
+class RenderIntegrator:
+    """Mirror of the reference's RenderIntegrator (integrator.rs:30-36)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._resident = {}
+
+    # integrator.rs:63-82
+    @classmethod
+    def new_from_json(cls, scene_path, config_path, base_dir=None):
+        h = C.c_void_p()
+        abi.check_host(abi.host_lib().rt_host_new_from_json(
+            os.fsencode(scene_path), os.fsencode(config_path), os.fsencode(base_dir) if base_dir else None, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls, json_scene, config, base_dir=None):
+        """integrator.rs:39-61 with the scene / config given as Python dicts (or JSON text)."""
+        s = json_scene if isinstance(json_scene, str) else json.dumps(json_scene)
+        c = config if isinstance(config, str) else json.dumps(config)
+        h = C.c_void_p()
+        abi.check_host(abi.host_lib().rt_host_new_from_strings(
+            s.encode(), c.encode(), os.fsencode(base_dir) if base_dir else None, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        for r in self._resident.values():
+            r.close()
+        self._resident = {}
+        if self._h:
+            abi.host_lib().rt_host_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # integrator.rs:163-192
+    def prepare(self):
+        abi.check_host(abi.host_lib().rt_host_prepare(self._h))
+        return self
+
+    @property
+    def scene(self):
+        """The RtScene POD (valid after prepare)."""
+        p = abi.host_lib().rt_host_scene(self._h)
+        if not p:
+            raise RuntimeError("call prepare() first")
+        return p
+
+    @property
+    def config(self):
+        """The RtConfig POD (editable in place)."""
+        return abi.host_lib().rt_host_config(self._h).contents
+
+    def bvh_depth(self):
+        return abi.host_lib().rt_host_bvh_depth(self._h)
+
+    def element_bbox(self, i):
+        mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+        abi.check_host(abi.host_lib().rt_host_element_bbox(self._h, i, mn, mx))
+        return tuple(mn), tuple(mx)
+
+    def resident(self, device=0):
+        """The scene resident on `device` (uploaded once, reused by repeated renders)."""
+        self.prepare()
+        if device not in self._resident:
+            self._resident[device] = ResidentScene(self.scene, device)
+        return self._resident[device]
+
+    # integrator.rs:161-249
+    def render(self, device=0):
+        stats = abi.RtStats()
+        abi.check_host(abi.host_lib().rt_host_render(self._h, int(device), C.byref(stats)))
+        return stats
+
+    def _buf(self, ptr):
+        cfg = self.config
+        n = cfg.img_width * cfg.img_height * 3
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(cfg.img_height, cfg.img_width, 3)
+
+    @property
+    def pixels(self):
+        return self._buf(abi.host_lib().rt_host_pixels(self._h))
+
+    @property
+    def sample_pixels(self):
+        return self._buf(abi.host_lib().rt_host_sample_pixels(self._h))
+
+    def set_pixels(self, pixels, sample_pixels=None):
+        p = np.ascontiguousarray(pixels, dtype=np.float64)
+        s = None if sample_pixels is None else np.ascontiguousarray(sample_pixels, dtype=np.float64)
+        abi.check_host(abi.host_lib().rt_host_set_pixels(self._h, p.ctypes.data, None if s is None else s.ctypes.data))
+
+    # integrator.rs:84-156
+    def save_to_png(self, png_path, samples_path=None):
+        abi.check_host(abi.host_lib().rt_host_save_to_png(
+            self._h, os.fsencode(png_path), os.fsencode(samples_path) if samples_path else None))

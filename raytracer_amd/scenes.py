@@ -1,0 +1,238 @@
+"""Synthetic inputs in the reference's JSON schema (render/config.rs:8-20,
+render/camera.rs:6-13, elements/mod.rs:48-55).
+
+The reference's own large meshes (input/obj/dragon.obj, xl_dragon.obj) are
+not distributed with it, so the benchmark scenes substitute a deterministic
+generated mesh of the same triangle count in the dragon's place.  Everything
+else -- camera, Cornell walls, the rotated metal box and the quad light with
+`attractor: true` -- carries the values of the reference's input/scene.json.
+"""
+import json
+import os
+
+import numpy as np
+
+
+def _v(x, y, z):
+    return {"x": float(x), "y": float(y), "z": float(z)}
+
+
+def _rgb(r, g, b):
+    return {"r": float(r), "g": float(g), "b": float(b)}
+
+
+def lambertian(r, g, b):
+    return {"Lambertian": {"albedo": _rgb(r, g, b)}}
+
+
+def metal(r, g, b, fuzz):
+    return {"Metal": {"albedo": _rgb(r, g, b), "fuzz": float(fuzz)}}
+
+
+def dielectric(ior):
+    return {"Dielectric": {"index_of_refraction": float(ior)}}
+
+
+def diffuse_light(r, g, b):
+    return {"DiffuseLight": {"albedo": _rgb(r, g, b)}}
+
+
+def camera(center=(278.0, 278.0, -800.0), look_at=(278.0, 278.0, 0.0), fov=40.0, defocus_angle=0.0, focus_dist=800.0):
+    """input/scene.json:2-16"""
+    return {
+        "camera_center": _v(*center),
+        "camera_look_at": _v(*look_at),
+        "camera_fov_vertical": float(fov),
+        "camera_defocus_angle": float(defocus_angle),
+        "camera_focus_dist": float(focus_dist),
+    }
+
+
+GREEN, RED, WHITE = (0.12, 0.45, 0.15), (0.65, 0.05, 0.05), (0.73, 0.73, 0.73)
+
+# The twelve wall / floor / ceiling triangles of input/scene.json:81-418, in
+# file order (two of them are exact duplicates of earlier ones, which is what
+# exercises the traversal's equal-t tie rule).
+_CORNELL_TRIANGLES = [
+    ((555, 0, 0), (555, 0, 555), (555, 555, 555), GREEN),
+    ((555, 0, 0), (555, 555, 555), (555, 555, 0), GREEN),
+    ((0, 0, 0), (0, 555, 555), (0, 0, 555), RED),
+    ((0, 0, 0), (0, 555, 0), (0, 555, 555), RED),
+    ((0, 555, 555), (555, 555, 0), (555, 555, 555), WHITE),
+    ((0, 0, 0), (0, 555, 0), (0, 555, 555), RED),
+    ((0, 0, 555), (555, 0, 555), (555, 0, 0), WHITE),
+    ((0, 0, 555), (555, 0, 0), (0, 0, 0), WHITE),
+    ((0, 555, 555), (555, 555, 0), (555, 555, 555), WHITE),
+    ((0, 555, 555), (0, 555, 0), (555, 555, 0), WHITE),
+    ((0, 0, 555), (0, 555, 555), (555, 0, 555), WHITE),
+    ((555, 0, 555), (0, 555, 555), (555, 555, 555), WHITE),
+]
+
+
+def cornell_elements(light_attractor=True):
+    """Box + walls + quad light of input/scene.json:47-447."""
+    els = [{
+        "JSONBox": {
+            "a": _v(0, 0, 0), "b": _v(165, 330, 165),
+            "material": metal(0.3, 0.3, 0.83, 0.1),
+            "transpose": _v(265, 0, 295),
+            "rotate": {"theta_x": 0.0, "theta_y": -0.25, "theta_z": 0.0},
+        }
+    }]
+    for v0, v1, v2, col in _CORNELL_TRIANGLES:
+        els.append({"JSONTriangle": {"v0": _v(*v0), "v1": _v(*v1), "v2": _v(*v2), "material": lambertian(*col)}})
+    light = {"q": _v(343, 554, 332), "u": _v(-130, 0, 0), "v": _v(0, 0, -105), "material": diffuse_light(10, 8, 8)}
+    if light_attractor:
+        light["attractor"] = True
+    els.append({"JSONQuad": light})
+    return els
+
+
+def sphere(center, radius, material, attractor=None, transpose=None):
+    s = {"center": _v(*center), "radius": float(radius), "material": material}
+    if attractor is not None:
+        s["attractor"] = bool(attractor)
+    if transpose is not None:
+        s["transpose"] = _v(*transpose)
+    return {"JSONSphere": s}
+
+
+def obj_element(filepath, material, transpose=None, rotate=None, scale=None):
+    o = {"filepath": filepath, "material": material}
+    if transpose is not None:
+        o["transpose"] = _v(*transpose)
+    if rotate is not None:
+        o["rotate"] = {"theta_x": float(rotate[0]), "theta_y": float(rotate[1]), "theta_z": float(rotate[2])}
+    if scale is not None:
+        o["scale"] = _v(*scale)
+    return {"JSONObj": o}
+
+
+def config(width, height, batch, max_batches, min_batches, max_depth=8, split="SAH", gamma=2.4, pixel_radius=2.0):
+    """input/config.json with the sizes replaced."""
+    c = {
+        "img_width": float(width), "img_height": float(height),
+        "sample_batch_size": int(batch), "max_sample_batches": int(max_batches), "min_sample_batches": int(min_batches),
+        "max_depth": int(max_depth),
+        "sky_color": _rgb(0.3, 0.5, 0.9),
+        "pixel_radius": float(pixel_radius),
+        "gamma_correction": float(gamma),
+    }
+    if split is not None:
+        c["bvh_split_method"] = split
+    return c
+
+
+def scene_c1(defocus_angle=0.0):
+    """Cornell box + Lambertian / Metal / Dielectric spheres standing where the
+    reference's scene.json puts its (undistributed) dragon mesh."""
+    els = [
+        sphere((150, 80, 170), 80, lambertian(0.43, 0.53, 0.43)),
+        sphere((310, 60, 90), 60, dielectric(1.5)),
+        sphere((450, 70, 200), 70, metal(0.8, 0.7, 0.6, 0.2)),
+    ] + cornell_elements()
+    return {"camera": camera(defocus_angle=defocus_angle), "elements": els}
+
+
+def config_c1(width=400, height=400):
+    """Fixed 64 spp: one batch of 64, so the z-test never runs."""
+    return config(width, height, 64, 1, 1)
+
+
+# ------------------------------------------------------------- synthetic mesh
+def knot_mesh(n_triangles=100_000, seed=7):
+    """A closed, consistently wound tube around a (2,3) torus knot with a
+    seeded sinusoidal displacement: exactly `n_triangles` triangles (must be
+    even).  Returns (vertices [V,3] f64, faces [T,3] int, 0-based)."""
+    if n_triangles % 2 or n_triangles < 24:
+        raise ValueError("n_triangles must be even and >= 24")
+    quads = n_triangles // 2
+    # nu segments along the curve, nv around the tube, nu*nv == quads
+    nv = 1
+    for cand in range(int(np.sqrt(quads / 20.0)), 2, -1):
+        if quads % cand == 0:
+            nv = cand
+            break
+    if nv < 3:
+        nv = 4 if quads % 4 == 0 else 3
+        if quads % nv:
+            raise ValueError("cannot factor the triangle count into a tube grid")
+    nu = quads // nv
+    rng = np.random.RandomState(seed)
+    ph = rng.uniform(0, 2 * np.pi, size=4)
+    u = np.arange(nu) * (2 * np.pi / nu)
+
+    def curve(t):
+        r = 2.0 + np.cos(3 * t)
+        return np.stack([r * np.cos(2 * t), r * np.sin(2 * t), -1.2 * np.sin(3 * t)], axis=-1)
+
+    h = 1e-4
+    c = curve(u)
+    d1 = (curve(u + h) - curve(u - h)) / (2 * h)
+    d2 = (curve(u + h) - 2 * c + curve(u - h)) / (h * h)
+    tan = d1 / np.linalg.norm(d1, axis=1, keepdims=True)
+    nrm = d2 - (d2 * tan).sum(1, keepdims=True) * tan
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    bin_ = np.cross(tan, nrm)
+    v = np.arange(nv) * (2 * np.pi / nv)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    radius = 0.42 * (1.0 + 0.18 * np.sin(9 * uu + ph[0]) * np.sin(4 * vv + ph[1]) + 0.07 * np.sin(31 * uu + 5 * vv + ph[2]))
+    pos = c[:, None, :] + radius[..., None] * (np.cos(vv)[..., None] * nrm[:, None, :] + np.sin(vv)[..., None] * bin_[:, None, :])
+    verts = pos.reshape(-1, 3)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    a = (i * nv + j).ravel()
+    b = (((i + 1) % nu) * nv + j).ravel()
+    cc = (((i + 1) % nu) * nv + (j + 1) % nv).ravel()
+    d = (i * nv + (j + 1) % nv).ravel()
+    faces = np.concatenate([np.stack([a, b, cc], 1), np.stack([a, cc, d], 1)], 0)
+    # orient outward: the face normal must point away from the tube's centre line
+    f0 = faces[0]
+    fn = np.cross(verts[f0[1]] - verts[f0[0]], verts[f0[2]] - verts[f0[0]])
+    out = verts[f0].mean(0) - c[0]
+    if np.dot(fn, out) < 0:
+        faces = faces[:, ::-1].copy()
+    assert faces.shape[0] == n_triangles
+    return verts, faces
+
+
+def write_obj(path, verts, faces):
+    """Plain `v` / `f` Wavefront file, 1-based indices, like input/obj/teapot.obj."""
+    with open(path, "w") as f:
+        f.write("# generated by raytracer_amd.scenes.knot_mesh\n")
+        np.savetxt(f, verts, fmt="v %.6f %.6f %.6f")
+        np.savetxt(f, faces + 1, fmt="f %d %d %d")
+
+
+def scene_c3(obj_path, defocus_angle=0.0):
+    """README-like scene: Cornell box + metal box + quad light + glass sphere +
+    a ~100k-triangle Lambertian mesh in the dragon's slot."""
+    els = [
+        obj_element(obj_path, lambertian(0.43, 0.53, 0.43), transpose=(190.0, 110.0, 170.0), rotate=(0.0, -3.2, 0.0),
+                    scale=(30.0, 30.0, 30.0)),
+        sphere((420, 70, 150), 70, dielectric(1.5)),
+    ] + cornell_elements()
+    return {"camera": camera(defocus_angle=defocus_angle), "elements": els}
+
+
+def config_c3(width=1200, height=1200):
+    """README render: batches of 20, at most 100 batches (2000 spp), at least 2."""
+    return config(width, height, 20, 100, 2)
+
+
+def materialize_c3(directory, n_triangles=100_000, width=1200, height=1200, seed=7):
+    """Write mesh.obj + scene.json + config.json for the C3 workload; returns the two JSON paths."""
+    os.makedirs(directory, exist_ok=True)
+    obj_path = os.path.join(directory, f"knot_{n_triangles}.obj")
+    if not os.path.exists(obj_path):
+        verts, faces = knot_mesh(n_triangles, seed)
+        tmp = obj_path + ".tmp"
+        write_obj(tmp, verts, faces)
+        os.replace(tmp, obj_path)
+    scene_path = os.path.join(directory, "scene.json")
+    config_path = os.path.join(directory, "config.json")
+    with open(scene_path, "w") as f:
+        json.dump(scene_c3(obj_path), f)
+    with open(config_path, "w") as f:
+        json.dump(config_c3(width, height), f)
+    return scene_path, config_path
