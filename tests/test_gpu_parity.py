@@ -1,0 +1,255 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Gates, from the task's north star:
+  * primary-ray hit element ids equal in >= 99.9 % of samples,
+  * hit t within 1e-4 relative,
+  * image within a stated per-pixel noise bound.
+The device path computes primitive tests in f64 with the reference's
+operation order, so in practice ids and t come out bit-identical; the tests
+assert the gate and report how far inside it the result is.
+"""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+from oracle import oracle
+
+from helpers import c1, knot_scene, random_rays
+
+pytestmark = pytest.mark.gpu
+
+ID_GATE = 0.999  # fraction of equal element ids
+T_RTOL = 1e-4    # relative tolerance on hit t
+
+
+def _check_hits(prim_g, t_g, prim_o, t_o):
+    same = prim_g == prim_o
+    frac = same.mean()
+    assert frac >= ID_GATE, f"only {frac:.6f} of hit ids agree"
+    both = same & (prim_o >= 0)
+    rel = np.abs(t_g[both] - t_o[both]) / np.abs(t_o[both])
+    assert rel.size == 0 or rel.max() <= T_RTOL, f"max relative t error {rel.max():.3e}"
+    return frac, (rel.max() if rel.size else 0.0), float((t_g[both] == t_o[both]).mean()) if rel.size else 1.0
+
+
+def test_device_present():
+    assert abi.hip_lib().rt_hip_device_count() >= 1
+
+
+@pytest.mark.parametrize("split", ["SAH", "Mid"])
+def test_primary_hits_c1(split):
+    ri = c1(width=96, height=96, batch=8, split=split)
+    cfg = ri.config.copy()
+    pg, tg = ri.resident(0).primary_hits(cfg)
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    frac, rel, exact = _check_hits(pg, tg, po, to)
+    assert frac == 1.0 and exact == 1.0, (frac, rel, exact)
+
+
+def test_primary_hits_with_defocus_uses_the_same_stream():
+    ri = c1(width=64, height=64, batch=4, defocus=0.6)
+    cfg = ri.config.copy()
+    cfg.seed = 99
+    pg, tg = ri.resident(0).primary_hits(cfg)
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    frac, rel, exact = _check_hits(pg, tg, po, to)
+    assert frac == 1.0 and exact == 1.0
+
+
+def test_primary_hits_mesh(tmp_scene_dir):
+    ri = knot_scene(tmp_scene_dir, 20000, 128, 128, 4, 1, 1)
+    cfg = ri.config.copy()
+    pg, tg = ri.resident(0).primary_hits(cfg)
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    frac, rel, exact = _check_hits(pg, tg, po, to)
+    assert frac == 1.0 and exact == 1.0, (frac, rel, exact)
+
+
+def test_primary_hits_row_shard():
+    ri = c1(width=40, height=50, batch=4)
+    cfg = ri.config.copy()
+    full_p, full_t = ri.resident(0).primary_hits(cfg)
+    cfg.row_first, cfg.row_stride = 3, 4
+    pg, tg = ri.resident(0).primary_hits(cfg)
+    assert np.array_equal(pg, full_p[3::4]) and np.array_equal(tg, full_t[3::4])
+
+
+def test_trace_random_rays(tmp_scene_dir):
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    o, d = random_rays(200_000, seed=3)
+    pg, tg = ri.resident(0).trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    frac, rel, exact = _check_hits(pg, tg, po, to)
+    assert frac == 1.0 and exact == 1.0, (frac, rel, exact)
+
+
+def test_trace_rays_ties_and_duplicates():
+    """Rays aimed exactly at shared triangle edges, box corners and the duplicated wall
+    triangles: the winner among equal-t candidates must be the reference's (later
+    leaf in depth-first order wins for triangles and quads)."""
+    ri = c1(width=8, height=8, batch=1)
+    rng = np.random.RandomState(5)
+    targets = []
+    for a in (0.0, 555.0):
+        for b in np.linspace(0.0, 555.0, 38):
+            targets += [(a, b, 555.0), (b, a, 555.0), (b, b, 555.0), (0.0, b, b), (555.0, b, b), (b, 0.0, b), (b, 555.0, b)]
+    targets = np.array(targets)
+    o = np.tile(np.array([[278.0, 278.0, -800.0]]), (len(targets), 1))
+    o2 = rng.uniform(100, 450, size=(len(targets), 3))
+    o = np.concatenate([o, o2])
+    tg_ = np.concatenate([targets, targets])
+    d = tg_ - o
+    pg, tg = ri.resident(0).trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    assert np.array_equal(pg, po)
+    assert np.array_equal(tg, to)
+
+
+def _image_checks(out_g, st_g, out_o, st_o, cfg, tight=1e-9):
+    lin_g, lin_o = out_g["linear"], out_o["linear"]
+    close = np.isclose(lin_g, lin_o, rtol=1e-9, atol=tight).all(axis=-1)
+    diff = np.abs(lin_g - lin_o)
+    rmse = float(np.sqrt((diff ** 2).mean()))
+    return close.mean(), rmse, diff.max()
+
+
+def test_render_matches_oracle_counter_mode():
+    """Same per-path random streams on both sides: the images agree to rounding except
+    where a last-bit difference in sin/cos/pow flips a path across an edge."""
+    ri = c1(width=64, height=64, batch=16, max_batches=1, min_batches=1)
+    cfg = ri.config.copy()
+    out_g, st_g = ri.resident(0).render(cfg)
+    out_o, st_o = oracle.render(ri.scene, cfg, 8)
+    frac, rmse, worst = _image_checks(out_g, st_g, out_o, st_o, cfg)
+    assert frac >= 0.99, f"only {frac:.4f} of pixels agree to 1e-9 (rmse {rmse:.3e}, worst {worst:.3e})"
+    assert np.array_equal(out_g["samples"], out_o["samples"])
+    assert np.allclose(out_g["sample_pixels"], out_o["sample_pixels"])
+    assert np.isclose(out_g["pixels"], out_o["pixels"], atol=1e-6).all(axis=-1).mean() >= 0.99
+    # ray counts: identical decisions -> identical counts (up to the few flipped paths)
+    assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-3 * st_o.rays
+    assert st_g.samples == st_o.samples == 64 * 64 * 16
+
+
+def test_render_adaptive_matches_oracle_counter_mode(tmp_scene_dir):
+    """z-test loop: batches of 8, up to 12 batches, first test after 4 batches."""
+    ri = knot_scene(tmp_scene_dir, 2000, 48, 48, 8, 12, 2)
+    cfg = ri.config.copy()
+    out_g, st_g = ri.resident(0).render(cfg)
+    out_o, st_o = oracle.render(ri.scene, cfg, 8)
+    same_counts = (out_g["samples"] == out_o["samples"]).mean()
+    assert same_counts >= 0.99, same_counts
+    ok = out_g["samples"] == out_o["samples"]
+    close = np.isclose(out_g["linear"], out_o["linear"], rtol=1e-9, atol=1e-9).all(axis=-1)
+    assert close[ok].mean() >= 0.98
+    # the adaptive loop really is exercised: some pixels stop early, some run to the end
+    assert out_g["samples"].min() < out_g["samples"].max()
+    assert out_g["samples"].max() == 8 * 12 and out_g["samples"].min() >= 8 * 4
+
+
+def test_render_vs_reference_rng_within_noise():
+    """Against the oracle in the reference's own RNG mode (one xoshiro256++ per row)
+    only the statistics can agree.  Per-pixel bound: 4 sigma of the difference of two
+    independent N-sample means, sigma estimated from two oracle runs with different
+    row seeds is not available in the reference, so the bound is taken from the
+    spread between the oracle's two modes, which are independent estimates too."""
+    ri = c1(width=40, height=40, batch=64, max_batches=1, min_batches=1)
+    cfg = ri.config.copy()
+    out_g, _ = ri.resident(0).render(cfg)
+    ref = cfg.copy()
+    ref.rng_mode = abi.RT_RNG_REF
+    out_r, _ = oracle.render(ri.scene, ref, 8)
+    ctr = cfg.copy()
+    ctr.seed = 12345
+    out_c, _ = oracle.render(ri.scene, ctr, 8)
+    lum = lambda a: (a * np.array([0.2126, 0.7152, 0.0722])).sum(-1)
+    noise = np.sqrt(((lum(out_c["linear"]) - lum(out_r["linear"])) ** 2).mean())
+    rmse = np.sqrt(((lum(out_g["linear"]) - lum(out_r["linear"])) ** 2).mean())
+    assert rmse <= 1.25 * noise + 1.0 / 255.0, (rmse, noise)
+    # unbiased: image means agree to a few percent
+    assert abs(out_g["linear"].mean() - out_r["linear"].mean()) <= 0.03 * out_r["linear"].mean()
+
+
+def test_render_is_deterministic_and_tiling_independent():
+    ri = c1(width=36, height=30, batch=8, max_batches=6, min_batches=1)
+    cfg = ri.config.copy()
+    a, _ = ri.resident(0).render(cfg)
+    b, _ = ri.resident(0).render(cfg)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # rows sharded 3 ways reproduce the full image bit for bit
+    for first in range(3):
+        sh = cfg.copy()
+        sh.row_first, sh.row_stride = first, 3
+        s, _ = ri.resident(0).render(sh)
+        for k in a:
+            assert np.array_equal(s[k], a[k][first::3]), (k, first)
+
+
+def test_early_termination_flag_does_not_change_pixels():
+    ri = c1(width=32, height=32, batch=16)
+    cfg = ri.config.copy()
+    a, sa = ri.resident(0).render(cfg)
+    cfg.flags = abi.RT_FLAG_EARLY_TERMINATE
+    b, sb = ri.resident(0).render(cfg)
+    assert np.array_equal(a["linear"], b["linear"])
+    assert sb.rays <= sa.rays
+
+
+def test_counters_and_timers():
+    ri = c1(width=32, height=32, batch=8)
+    cfg = ri.config.copy()
+    cfg.flags = abi.RT_FLAG_TIME_KERNELS | abi.RT_FLAG_COUNT_VISITS
+    out, st = ri.resident(0).render(cfg)
+    _, so = oracle.render(ri.scene, ri.config.copy(), 4)
+    assert st.trace_launches == cfg.max_depth and st.trace_kernel_ms > 0
+    assert st.rays_by_depth[0] == 32 * 32 * 8
+    assert sum(st.rays_by_depth) == st.rays
+    # the device visits a superset of the oracle's nodes (boxes rounded outward to f32)
+    assert st.leaf_tests >= 0.999 * so.leaf_tests and st.leaf_tests <= 1.02 * so.leaf_tests
+    assert st.node_visits >= 0.999 * so.node_visits and st.node_visits <= 1.02 * so.node_visits
+
+
+def test_chunked_rounds_give_the_same_image(monkeypatch):
+    ri = c1(width=32, height=32, batch=8, max_batches=3, min_batches=0)
+    cfg = ri.config.copy()
+    a, _ = ri.resident(0).render(cfg)
+    monkeypatch.setenv("RT_HIP_MAX_PATHS", "1000")
+    b, _ = ri.resident(0).render(cfg)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_host_integrator_render_and_png(tmp_path):
+    ri = c1(width=32, height=24, batch=8)
+    st = ri.render(0)
+    assert st.rays > 0
+    px = ri.pixels
+    assert px.shape == (24, 32, 3) and px.min() >= 0.0 and px.max() <= 1.0 and px.max() > 0.1
+    cfg = ri.config.copy()
+    out, _ = ri.resident(0).render(cfg)
+    assert np.array_equal(out["pixels"], px)
+    p, s = str(tmp_path / "render.png"), str(tmp_path / "samples.png")
+    ri.save_to_png(p, s)
+    from test_host import read_png
+    w, h, rgb, _ = read_png(p)
+    assert (w, h) == (32, 24)
+    expect = (np.clip(px, 0, 1) * 255.0).astype(np.uint8)
+    assert np.array_equal(rgb, expect)
+
+
+def test_device_output_buffers():
+    torch = pytest.importorskip("torch")
+    ri = c1(width=32, height=32, batch=8)
+    cfg = ri.config.copy()
+    a, _ = ri.resident(0).render(cfg)
+    dev = {
+        "pixels": torch.empty(32, 32, 3, dtype=torch.float64, device="cuda:0"),
+        "sample_pixels": torch.empty(32, 32, 3, dtype=torch.float64, device="cuda:0"),
+        "linear": torch.empty(32, 32, 3, dtype=torch.float64, device="cuda:0"),
+        "samples": torch.empty(32, 32, dtype=torch.int32, device="cuda:0"),
+    }
+    ri.resident(0).render(cfg, device_out=dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev["pixels"].cpu().numpy(), a["pixels"])
+    assert np.array_equal(dev["linear"].cpu().numpy(), a["linear"])
+    assert np.array_equal(dev["samples"].cpu().numpy().astype(np.uint32), a["samples"])
