@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--early-terminate", action="store_true", help="set RT_FLAG_EARLY_TERMINATE (same pixels, fewer rays)")
+    ap.add_argument("--reference-visits", action="store_true", help="set RT_FLAG_REFERENCE_VISIT_RULE (same pixels, more node visits)")
     args = ap.parse_args()
 
     import torch
@@ -70,7 +71,8 @@ def main():
     t_upload = time.time() - t_up0
     sc = ri.scene.contents
     cfg = parallel.shard_config(ri.config, rank, world)
-    cfg.flags = abi.RT_FLAG_TIME_KERNELS | (abi.RT_FLAG_EARLY_TERMINATE if args.early_terminate else 0)
+    opt_flags = (abi.RT_FLAG_EARLY_TERMINATE if args.early_terminate else 0) | (abi.RT_FLAG_REFERENCE_VISIT_RULE if args.reference_visits else 0)
+    cfg.flags = abi.RT_FLAG_TIME_KERNELS | opt_flags
     H, W = cfg.img_height, cfg.img_width
     n_rows = cfg.n_rows()
     dev = torch.device("cuda", local_rank)
@@ -99,7 +101,8 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    rays = trace_ms = launches = other_ms = 0.0
+    rays = trace_ms = launches = other_ms = shade_ms = 0.0
+    ms_by_depth = [0.0] * 16
     samples = 0
     for _ in range(args.steps):
         st, img, heat = step()
@@ -107,6 +110,8 @@ def main():
         trace_ms += st.trace_kernel_ms
         launches += st.trace_launches
         other_ms += st.other_kernel_ms
+        shade_ms += st.shade_kernel_ms
+        ms_by_depth = [a + b for a, b in zip(ms_by_depth, st.trace_ms_by_depth)]
         samples += st.samples
     sync()
     elapsed = time.perf_counter() - t0
@@ -125,7 +130,7 @@ def main():
 
     # ---- untimed instrumented render: device-side visit counts for the byte model
     cfg_cnt = cfg.copy()
-    cfg_cnt.flags = abi.RT_FLAG_COUNT_VISITS | (abi.RT_FLAG_EARLY_TERMINATE if args.early_terminate else 0)
+    cfg_cnt.flags = abi.RT_FLAG_COUNT_VISITS | opt_flags
     _, st_cnt = res.render(cfg_cnt, device_out=out)
     v_int_dev = st_cnt.node_visits / max(st_cnt.rays, 1)
     v_leaf_dev = st_cnt.leaf_tests / max(st_cnt.rays, 1)
@@ -191,7 +196,7 @@ def main():
                             f"(min {cfg.min_sample_batches}), depth {cfg.max_depth}, SAH BVH, adaptive z-test",
                 "elements": sc.n_elements, "bvh_nodes": sc.n_nodes, "bvh_depth": ri.bvh_depth(),
                 "rows_per_rank": n_rows, "parallelism": f"rows interleaved over {world} GPU(s), gather to rank 0",
-                "early_terminate": bool(args.early_terminate),
+                "early_terminate": bool(args.early_terminate), "reference_visit_rule": bool(args.reference_visits),
             },
             "rays_per_step": rays_all / args.steps,
             "mean_spp": samples_all / args.steps / (W * H),
@@ -214,7 +219,9 @@ def main():
                 "launches": launches / args.steps,
                 "avg_launch_ms": trace_ms / max(launches, 1),
                 "kernel_ms_per_step": trace_ms / args.steps,
+                "shade_kernel_ms_per_step": shade_ms / args.steps,
                 "other_kernels_ms_per_step": other_ms / args.steps,
+                "kernel_ms_by_depth_per_step": [x / args.steps for x in ms_by_depth[:cfg.max_depth]],
                 "max_rank_kernel_ms_per_step": trace_ms_max / args.steps,
             },
             "cpu_baseline": cpu,

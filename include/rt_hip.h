@@ -66,6 +66,18 @@ extern "C" {
 #define RT_FLAG_TIME_KERNELS 1
 #define RT_FLAG_COUNT_VISITS 2
 #define RT_FLAG_EARLY_TERMINATE 4
+/* RT_FLAG_REFERENCE_VISIT_RULE  The reference enters the right child of a
+ *                         BVH node WITHOUT testing its box after a hit in the
+ *                         left subtree (bvh_node_sah.rs:215-216).  A child
+ *                         whose box the ray misses can only hold a hit if a
+ *                         primitive sticks out of its box (the reference's box
+ *                         for a quad that is not axis-aligned, quad.rs:86), so
+ *                         the device skips such children when every box of the
+ *                         uploaded scene bounds its contents and follows the
+ *                         reference's rule otherwise.  This flag forces the
+ *                         reference's rule in all cases (same pixels, more node
+ *                         visits). */
+#define RT_FLAG_REFERENCE_VISIT_RULE 8
 
 /* RtImage.memory */
 #define RT_MEM_HOST 0
@@ -203,17 +215,22 @@ typedef struct RtImage {
 /* Counters the reference lacks (it has no ray counter).  A "ray" is one BVH
  * closest-hit query, i.e. one call of BVH_SAH::hit at integrator.rs:359. */
 typedef struct RtStats {
-  uint64_t rays;                           /* BVH closest-hit queries */
-  uint64_t rays_by_depth[RT_MAX_DEPTH_STATS]; /* index = bounce number, 0 = primary */
-  uint64_t samples;                        /* primary samples (paths) */
-  uint64_t batches;                        /* batch rounds executed */
+  uint64_t rays;        /* BVH closest-hit queries of the samples that count (what the reference would trace) */
+  uint64_t rays_traced; /* queries actually executed: the device also traces batches speculatively
+                           beyond a pixel's stopping batch and drops them (oracle: == rays) */
+  uint64_t rays_by_depth[RT_MAX_DEPTH_STATS]; /* executed queries per bounce number, 0 = primary */
+  uint64_t samples;     /* primary samples (paths) that count */
+  uint64_t batches;     /* device: rounds executed (a round traces several batches); oracle: 0 */
   uint64_t node_visits;  /* internal nodes entered (oracle; device if instrumented) */
   uint64_t box_tests;    /* Aabb::hit calls */
   uint64_t leaf_tests;   /* Element::hit calls from BVH leaves */
   double wall_ms;        /* call wall time, scene already resident */
-  double trace_kernel_ms;    /* sum of device durations of the trace/shade kernel */
+  /* device durations, filled when RT_FLAG_TIME_KERNELS is set */
+  double trace_kernel_ms;    /* sum over launches of the closest-hit kernel (k_extend) */
   uint64_t trace_launches;   /* number of launches of that kernel */
-  double other_kernel_ms;    /* generate + accumulate/z-test + finalize kernels */
+  double shade_kernel_ms;    /* sum over launches of the shading kernel */
+  double other_kernel_ms;    /* generate + accumulate/z-test kernels */
+  double trace_ms_by_depth[RT_MAX_DEPTH_STATS]; /* k_extend time per bounce number */
 } RtStats;
 
 typedef struct RtSceneHandle RtSceneHandle;

@@ -829,6 +829,7 @@ int rt_oracle_render(const RtScene *sc, const RtConfig *cfg, RtImage *out, RtSta
   if (stats) {
     memset(stats, 0, sizeof *stats);
     stats->rays = job.total.rays;
+    stats->rays_traced = job.total.rays;
     stats->samples = job.total.samples;
     stats->node_visits = job.total.node_visits;
     stats->box_tests = job.total.box_tests;

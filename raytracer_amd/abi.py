@@ -20,7 +20,7 @@ RT_ERR_UNSUPPORTED = -4
 RT_PRIM_SPHERE, RT_PRIM_QUAD, RT_PRIM_TRIANGLE = 0, 1, 2
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RT_RNG_REF, RT_RNG_CTR = 0, 1
-RT_FLAG_TIME_KERNELS, RT_FLAG_COUNT_VISITS, RT_FLAG_EARLY_TERMINATE = 1, 2, 4
+RT_FLAG_TIME_KERNELS, RT_FLAG_COUNT_VISITS, RT_FLAG_EARLY_TERMINATE, RT_FLAG_REFERENCE_VISIT_RULE = 1, 2, 4, 8
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 RT_MAX_DEPTH_STATS = 16
 
@@ -120,6 +120,7 @@ class RtImage(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [
         ("rays", C.c_uint64),
+        ("rays_traced", C.c_uint64),
         ("rays_by_depth", C.c_uint64 * RT_MAX_DEPTH_STATS),
         ("samples", C.c_uint64),
         ("batches", C.c_uint64),
@@ -129,7 +130,9 @@ class RtStats(C.Structure):
         ("wall_ms", C.c_double),
         ("trace_kernel_ms", C.c_double),
         ("trace_launches", C.c_uint64),
+        ("shade_kernel_ms", C.c_double),
         ("other_kernel_ms", C.c_double),
+        ("trace_ms_by_depth", C.c_double * RT_MAX_DEPTH_STATS),
     ]
 
 

@@ -3,7 +3,8 @@
 // keeps the reference's operation order (this translation unit is compiled
 // with -ffp-contract=off: the Rust reference never fuses a multiply-add), so
 // that a primitive test returns the same t bits as the reference's.  Only the
-// BVH child boxes are stored in f32, rounded outward.
+// BVH child boxes are stored and tested in f32, rounded outward, which can
+// add box visits but never removes one.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -46,6 +47,16 @@ struct __attribute__((aligned(16))) DevTriangle {
 };
 static_assert(sizeof(DevTriangle) == 80, "triangle record");
 
+// 64-byte record read when a triangle hit is shaded: Triangle::new's unit
+// normal (triangle.rs:58) and the triangle's Material inlined.
+struct __attribute__((aligned(64))) DevTriShade {
+  double normal[3], albedo[3];
+  double param;
+  int32_t kind;
+  int32_t pad;
+};
+static_assert(sizeof(DevTriShade) == 64, "triangle shade record");
+
 struct DevQuad {
   double q[3], u[3], v[3], normal[3], w[3];
   double d, area;
@@ -66,7 +77,7 @@ struct DevMaterial {
 struct DevScene {
   const DevNode *nodes;
   const DevTriangle *triangles;
-  const double *tri_normals;  // 3 per triangle, Triangle::new's normal
+  const DevTriShade *tri_shade;
   const DevQuad *quads;
   const DevSphere *spheres;
   const DevMaterial *materials;
@@ -74,6 +85,7 @@ struct DevScene {
   int32_t n_attractors;
   uint32_t root;        // ref of nodes[0] of the reference array
   int32_t stack_depth;  // LDS stack entries per lane
+  int32_t quirk;        // 1 when some child box does not contain the primitives below it
   RtCamera camera;
 };
 
@@ -287,113 +299,202 @@ RT_DEV bool sphere_hit(const DevSphere &s, const Ray &r, double tmin, double tma
   return false;
 }
 
-// aabb.rs:187-204 on an outward-rounded f32 box: evaluated in f64 with the
-// reference's expression, so on a box whose corners are exactly representable
-// in f32 the decision is the reference's, and otherwise the slightly larger
-// box can only add visits (a superset of the reference's leaves is tested).
-RT_DEV bool slab_hit(const float *bmin, const float *bmax, const Ray &r) {
-  double lo, hi;
-  lo = (double)(r.d.x < 0.0 ? bmax[0] : bmin[0]);
-  hi = (double)(r.d.x < 0.0 ? bmin[0] : bmax[0]);
-  double ray_min = (lo - r.o.x) * r.inv.x;
-  double ray_max = (hi - r.o.x) * r.inv.x;
-  lo = (double)(r.d.y < 0.0 ? bmax[1] : bmin[1]);
-  hi = (double)(r.d.y < 0.0 ? bmin[1] : bmax[1]);
-  double y_min = (lo - r.o.y) * r.inv.y;
-  double y_max = (hi - r.o.y) * r.inv.y;
-  ray_min = fmax(ray_min, y_min);
-  ray_max = fmin(ray_max, y_max);
-  lo = (double)(r.d.z < 0.0 ? bmax[2] : bmin[2]);
-  hi = (double)(r.d.z < 0.0 ? bmin[2] : bmax[2]);
-  double z_min = (lo - r.o.z) * r.inv.z;
-  double z_max = (hi - r.o.z) * r.inv.z;
-  ray_min = fmax(ray_min, z_min);
-  ray_max = fmin(ray_max, z_max);
-  return fmax(ray_min, 0.0) <= ray_max;
-}
-
 // ------------------------------------------------ BVH closest-hit query
-// Restates BVH_SAH::hit (bvh_node_sah.rs:162-253) iteratively.  The
-// reference's recursion is an ordered depth-first walk, left child first,
-// that keeps the best t so far in ray_t.interval_max; a later leaf replaces
-// the current hit when its t lies in [tmin, best] (inclusive for triangles
-// and quads, strict for spheres).  Its one irregularity is kept: after the
-// left subtree of a node returned a hit, the right child is entered WITHOUT
-// testing its box (bvh_node_sah.rs:215-216).  `hitmask` bit s records whether
-// a hit was accepted since the entry at stack position s was pushed.
+// Restates BVH_SAH::hit (bvh_node_sah.rs:162-253).  The reference's recursion
+// is an ordered depth-first walk, left child first, that keeps the best t so
+// far in ray_t.interval_max; a later leaf replaces the current hit when its t
+// lies in [tmin, best] (inclusive for triangles and quads, strict for
+// spheres).  Child boxes are never culled against t (aabb.rs:187-204 ignores
+// ray_t), so which leaves get tested depends on the boxes alone -- with one
+// irregularity: after the left subtree of a node returned a hit, the right
+// child is entered WITHOUT testing its box (bvh_node_sah.rs:215-216).
 //
-// `stack` points at this lane's slot of an LDS array laid out
-// [level][thread]; consecutive levels are `stride` entries apart, so a wave's
-// accesses to one level touch 64 consecutive dwords (no bank conflicts).
+// That irregularity can only change a result when a primitive sticks out of
+// the boxes above it (the reference's Quad bounding box is wrong for quads
+// that are not axis-aligned, quad.rs:86).  The scene upload checks whether
+// every child box contains the primitives below it:
+//   QUIRK == false  all boxes bound their contents: a right child whose box
+//                   the ray misses is never entered (it cannot hold a hit);
+//   QUIRK == true   some box does not: the right child is pushed with a
+//                   "box passed" bit and `hitmask` bit s records whether a hit
+//                   was accepted since stack entry s was pushed, exactly
+//                   reproducing the reference's visit rule.
 struct Hit {
   double t;
   uint32_t ref;  // leaf ref of the primitive hit, kRefNone on a miss
 };
 
-template <bool COUNT>
-RT_DEV Hit bvh_closest_hit(const DevScene &sc, const Ray &r, uint32_t *stack, int stride, uint32_t *n_nodes, uint32_t *n_leaves) {
-  Hit best{kF64Max, kRefNone};
-  uint64_t hitmask = 0;
-  int sp = 0;
-  uint32_t cur = sc.root;
-  for (;;) {
-    bool pop = false;
-    if (!(cur & kRefLeaf)) {
-      const DevNode &n = sc.nodes[cur & kRefIndexMask];
-      // four 16-byte loads
-      const float4 *p = reinterpret_cast<const float4 *>(&n);
-      float4 q0 = p[0], q1 = p[1], q2 = p[2];
-      uint2 kids = *reinterpret_cast<const uint2 *>(&n.left);
-      float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-      float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-      if (COUNT) (*n_nodes)++;
-      bool hl = slab_hit(lmin, lmax, r);
-      bool hr = slab_hit(rmin, rmax, r);
-      if (hl) {
-        stack[sp * stride] = kids.y | (hr ? kRefFlag : 0u);
-        hitmask &= ~(1ull << sp);
-        sp++;
-        cur = kids.x;
-      } else if (hr) {
-        cur = kids.y;
-      } else {
-        pop = true;
-      }
+constexpr uint32_t kDone = 0xffffffffu;  // no node left (has the leaf bit set on purpose)
+constexpr uint32_t kWait = 0xfffffffeu;  // QUIRK: a pop is waiting for deferred leaf tests
+constexpr int kMaxLeafQueue = 4;         // deferred leaf tests per lane
+
+// f32 copy of a ray for the box tests.  The origin is widened by its own
+// rounding error: o_up >= o >= o_dn, so that with boxes rounded outward the
+// computed slab interval contains the exact one.
+struct RayF {
+  float oux, ouy, ouz;  // origin rounded up
+  float odx, ody, odz;  // origin rounded down
+  float ix, iy, iz;     // 1/direction
+};
+RT_DEV RayF make_rayf(d3 o, d3 d) {
+  RayF f;
+  float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float u2 = 1.1920929e-7f;  // 2^-23: twice the rounding error of the conversion
+  float ex = fabsf(ox) * u2 + 1e-30f, ey = fabsf(oy) * u2 + 1e-30f, ez = fabsf(oz) * u2 + 1e-30f;
+  f.oux = ox + ex; f.ouy = oy + ey; f.ouz = oz + ez;
+  f.odx = ox - ex; f.ody = oy - ey; f.odz = oz - ez;
+  // 1/d to within two f32 roundings; a zero component gives +-inf like the reference's 1.0 / d
+  f.ix = 1.0f / (float)d.x; f.iy = 1.0f / (float)d.y; f.iz = 1.0f / (float)d.z;
+  // a component too small for f32 must keep its sign and become +-inf, not flip through zero
+  if ((float)d.x == 0.0f) f.ix = copysignf(INFINITY, (float)copysign(1.0, d.x));
+  if ((float)d.y == 0.0f) f.iy = copysignf(INFINITY, (float)copysign(1.0, d.y));
+  if ((float)d.z == 0.0f) f.iz = copysignf(INFINITY, (float)copysign(1.0, d.z));
+  return f;
+}
+// Conservative slab test (aabb.rs:187-204 evaluated in f32): the min corner is
+// always paired with the rounded-up origin and the max corner with the
+// rounded-down one, which makes the near plane nearer and the far plane
+// farther for either sign of the direction; the far side is widened by the
+// relative rounding error of the f32 operations.  fminf/fmaxf return the
+// non-NaN operand like f64::min/max.  Passes whenever the reference's test does.
+RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayF &f) {
+  float tlx = (bminx - f.oux) * f.ix, thx = (bmaxx - f.odx) * f.ix;
+  float tly = (bminy - f.ouy) * f.iy, thy = (bmaxy - f.ody) * f.iy;
+  float tlz = (bminz - f.ouz) * f.iz, thz = (bmaxz - f.odz) * f.iz;
+  float tn = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), 0.0f));
+  float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+  return tn <= tf * 1.000001f;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Per-lane traversal state.  `stack` / `leafq` point at this lane's slot of
+// LDS arrays laid out [level][lane]; consecutive levels are `stride` entries
+// apart, so a wave's accesses to one level touch 64 consecutive dwords.
+struct Traversal {
+  uint32_t cur;      // node ref, leaf ref, kDone or kWait
+  int sp;            // stack entries
+  int qn;            // deferred leaves
+  uint64_t hitmask;  // QUIRK: bit s = a hit was accepted since stack entry s was pushed
+  u16x2 m01, m23;    // QUIRK: per deferred leaf, the lowest stack height since it was queued
+  Hit best;
+};
+
+RT_DEV void trav_begin(const DevScene &sc, Traversal &tv) {
+  tv.cur = sc.root;
+  tv.sp = 0;
+  tv.qn = 0;
+  tv.hitmask = 0;
+  tv.m01 = u16x2{0, 0};
+  tv.m23 = u16x2{0, 0};
+  tv.best.t = kF64Max;
+  tv.best.ref = kRefNone;
+}
+
+// Take the next node off the stack.
+//   !QUIRK: entries are right children whose box the ray hits.
+//   QUIRK : every right child of a node whose left box was hit is on the stack
+//           with a "box passed" bit; an entry without the bit is entered only
+//           if a hit was accepted since it was pushed (bvh_node_sah.rs:211-216).
+//           While leaf tests queued since then are still pending that is not
+//           known yet, and the lane waits (kWait) for the next leaf phase.
+template <bool QUIRK>
+RT_DEV void trav_pop(Traversal &tv, const uint32_t *stack, int stride) {
+  if (!QUIRK) {
+    if (tv.sp == 0) {
+      tv.cur = kDone;
     } else {
-      uint32_t kind = (cur >> kRefKindShift) & 3u;
-      uint32_t idx = cur & kRefIndexMask;
-      double t;
-      bool ok;
-      if (COUNT) (*n_leaves)++;
-      if (kind == RT_PRIM_TRIANGLE) {
-        const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[idx]);
-        double2 a = p[0], b = p[1], c = p[2], d = p[3];
-        double e2z = reinterpret_cast<const double *>(p)[8];
-        ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(d.x, d.y, e2z), r, kTMin, best.t, t);
-      } else if (kind == RT_PRIM_QUAD) {
-        ok = quad_hit(sc.quads[idx], r, kTMin, best.t, t);
-      } else {
-        ok = sphere_hit(sc.spheres[idx], r, kTMin, best.t, t);
-      }
-      if (ok) {
-        best.t = t;
-        best.ref = cur;
-        hitmask = ~0ull;
-      }
-      pop = true;
+      tv.sp--;
+      tv.cur = stack[tv.sp * stride];
     }
-    if (pop) {
-      for (;;) {
-        if (sp == 0) return best;
-        sp--;
-        uint32_t e = stack[sp * stride];
-        bool left_hit = (hitmask >> sp) & 1ull;
-        if ((e & kRefFlag) || left_hit) {
-          cur = e & ~kRefFlag;
-          break;
-        }
+  } else {
+    for (;;) {
+      if (tv.sp == 0) {
+        tv.cur = kDone;
+        return;
+      }
+      uint32_t e = stack[(tv.sp - 1) * stride];
+      bool enter = (e & kRefFlag) || ((tv.hitmask >> (tv.sp - 1)) & 1ull);
+      if (!enter && tv.qn > 0) {
+        tv.cur = kWait;
+        return;
+      }
+      tv.sp--;
+      unsigned short h = (unsigned short)tv.sp;
+      tv.m01 = __builtin_elementwise_min(tv.m01, u16x2{h, h});
+      tv.m23 = __builtin_elementwise_min(tv.m23, u16x2{h, h});
+      if (enter) {
+        tv.cur = e & ~kRefFlag;
+        return;
       }
     }
+  }
+}
+
+// One internal-node step: fetch the 64-byte node, test both child boxes,
+// descend / push / pop.
+template <bool QUIRK>
+RT_DEV void trav_node(const DevScene &sc, const RayF &f, Traversal &tv, uint32_t *stack, int stride) {
+  const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
+  float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+  uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+  bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f);
+  bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f);
+  if (hl) {
+    if (QUIRK) {
+      stack[tv.sp * stride] = right | (hr ? kRefFlag : 0u);
+      tv.hitmask &= ~(1ull << tv.sp);
+      tv.sp++;
+    } else if (hr) {
+      stack[tv.sp * stride] = right;
+      tv.sp++;
+    }
+    tv.cur = left;
+  } else if (hr) {
+    tv.cur = right;
+  } else {
+    trav_pop<QUIRK>(tv, stack, stride);
+  }
+}
+
+// Queue the leaf in `cur` for the next leaf phase and move on.
+template <bool QUIRK>
+RT_DEV void trav_defer_leaf(Traversal &tv, const uint32_t *stack, uint32_t *leafq, int stride) {
+  leafq[tv.qn * stride] = tv.cur;
+  if (QUIRK) {
+    unsigned short h = (unsigned short)tv.sp;
+    if (tv.qn == 0) tv.m01.x = h;
+    else if (tv.qn == 1) tv.m01.y = h;
+    else if (tv.qn == 2) tv.m23.x = h;
+    else tv.m23.y = h;
+  }
+  tv.qn++;
+  trav_pop<QUIRK>(tv, stack, stride);
+}
+
+// The primitive test of the reference with the interval [kTMin, best.t]
+// (triangle/quad inclusive, sphere strict).  `height` = how many of the
+// current stack entries were already there when the leaf was reached.
+template <bool QUIRK>
+RT_DEV void trav_test_leaf(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf, int height) {
+  Ray r = {o, d, D3(0, 0, 0)};
+  uint32_t kind = (leaf >> kRefKindShift) & 3u;
+  uint32_t idx = leaf & kRefIndexMask;
+  double t;
+  bool ok;
+  if (kind == RT_PRIM_TRIANGLE) {
+    const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[idx]);
+    double2 a = p[0], b = p[1], c = p[2], dd = p[3], e = p[4];
+    ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);
+  } else if (kind == RT_PRIM_QUAD) {
+    ok = quad_hit(sc.quads[idx], r, kTMin, tv.best.t, t);
+  } else {
+    ok = sphere_hit(sc.spheres[idx], r, kTMin, tv.best.t, t);
+  }
+  if (ok) {
+    tv.best.t = t;
+    tv.best.ref = leaf;
+    if (QUIRK) tv.hitmask |= (height >= 64) ? ~0ull : ((1ull << height) - 1ull);
   }
 }
 

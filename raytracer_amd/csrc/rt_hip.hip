@@ -56,16 +56,41 @@ static int fail(int code, const std::string &msg) {
 constexpr int32_t kFlagTimeKernels = RT_FLAG_TIME_KERNELS;
 constexpr int32_t kFlagCountVisits = RT_FLAG_COUNT_VISITS;
 constexpr int32_t kFlagEarlyTerminate = RT_FLAG_EARLY_TERMINATE;
+constexpr int32_t kFlagReferenceVisitRule = RT_FLAG_REFERENCE_VISIT_RULE;
 
 // ==================================================================== queues
 // SoA path state.  One "queue" holds the rays about to be traced at a bounce.
+// A queue is split into kRegions regions of `cap` entries each; region r holds
+// entries [r*cap, r*cap + count[r]).  A path stays in its region for its whole
+// life, every region has its own append counter (one global atomic word serves
+// only ~90 M appends/s, far less than the kernels produce), and region r is
+// always processed by workgroups with blockIdx % kRegions == r, i.e. by one XCD.
+constexpr int kRegions = 64;
+constexpr int kCounterStride = 32;  // uint32 words between two counters: one 128-byte line each
+
 struct PathQueue {
   double *ox, *oy, *oz;  // origin
   double *dx, *dy, *dz;  // normalised direction
   double *tx, *ty, *tz;  // throughput
   uint64_t *rng;         // SplitMix64 counter
-  uint32_t *pid;         // sample * n_slots + slot
+  uint32_t *pid;         // path id within the round
+  uint32_t cap;          // entries per region
 };
+
+// Where entry j of n goes when a kernel fills a queue from scratch: regions get
+// equal contiguous shares (whole waves), and their counts follow from n alone.
+__device__ __forceinline__ uint32_t region_share(int64_t n) { return (uint32_t)(((n + kRegions - 1) / kRegions + 63) / 64 * 64); }
+__device__ __forceinline__ uint32_t region_place(int64_t j, uint32_t share, uint32_t cap) {
+  uint32_t r = (uint32_t)(j / share);
+  return r * cap + (uint32_t)(j - (int64_t)r * share);
+}
+__device__ __forceinline__ void region_publish_counts(int64_t n, uint32_t share, uint32_t *counts) {
+  // called by one workgroup: thread r < kRegions publishes region r's count
+  if (threadIdx.x < kRegions) {
+    int64_t left = n - (int64_t)threadIdx.x * share;
+    counts[threadIdx.x * kCounterStride] = (uint32_t)(left < 0 ? 0 : (left > share ? share : left));
+  }
+}
 
 struct HitBuffer {
   double *t;
@@ -95,13 +120,19 @@ __device__ __forceinline__ uint32_t xcd_logical_block(uint32_t b, uint32_t nbloc
 }
 
 // ================================================================== generate
+// One lane per (active pixel slot, batch g of the group, sample i); the path
+// id is (slot * G + g) * S + i, so the samples of one batch of one pixel are
+// adjacent (coherent primary rays, contiguous per-path outputs).
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
-                                                   int32_t batch, PathQueue q, double *weights, uint32_t *qcount0) {
-  int64_t n = (int64_t)n_slots * rp.S;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *qcount0 = (uint32_t)n;
+                                                   int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
+  int64_t n = (int64_t)n_slots * G * rp.S;
+  const uint32_t share = region_share(n);
+  if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
   uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
   for (int64_t j = (int64_t)lb * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    int32_t slot = (int32_t)(j / rp.S), i = (int32_t)(j % rp.S);
+    int32_t i = (int32_t)(j % rp.S);
+    int64_t sg = j / rp.S;
+    int32_t g = (int32_t)(sg % G), slot = (int32_t)(sg / G);
     uint32_t p = active[slot];
     int32_t x = (int32_t)(p % (uint32_t)rp.width);
     int32_t y = rp.row_first + (int32_t)(p / (uint32_t)rp.width) * rp.row_stride;
@@ -111,7 +142,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     double sy = ((double)sobol_sample((uint32_t)i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
     double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
     double w = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
-    uint64_t rng = rng_seed_path((uint64_t)y * (uint64_t)rp.width + (uint64_t)x, (uint64_t)batch, (uint64_t)i, rp.seed);
+    uint64_t rng = rng_seed_path((uint64_t)y * (uint64_t)rp.width + (uint64_t)x, (uint64_t)(batch0 + g), (uint64_t)i, rp.seed);
     // camera.rs:95-120
     d3 center = ld3(sc.camera.camera_center);
     d3 origin = center;
@@ -122,35 +153,163 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
     d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
     d3 dir = normalized(pixel_sample - origin);
-    uint32_t pid = (uint32_t)i * (uint32_t)n_slots + (uint32_t)slot;
-    q.ox[j] = origin.x; q.oy[j] = origin.y; q.oz[j] = origin.z;
-    q.dx[j] = dir.x; q.dy[j] = dir.y; q.dz[j] = dir.z;
-    q.tx[j] = 1.0; q.ty[j] = 1.0; q.tz[j] = 1.0;
-    q.rng[j] = rng;
-    q.pid[j] = pid;
-    weights[pid] = w;
+    uint32_t e = region_place(j, share, q.cap);
+    q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+    q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
+    q.tx[e] = 1.0; q.ty[e] = 1.0; q.tz[e] = 1.0;
+    q.rng[e] = rng;
+    q.pid[e] = (uint32_t)j;
+    weights[j] = w;
   }
 }
 
 // ==================================================================== extend
-extern __shared__ uint32_t g_stack[];
+// BVH closest-hit queries for one ray queue: the dominant kernel.
+//
+// * One wave per workgroup, persistent.  A wave claims rays in chunks of
+//   kClaim from the regions of the queue (its own region first -- workgroups
+//   with equal blockIdx % 8 share an XCD and so an L2 -- then the others), one
+//   device atomic per chunk, and refills its idle lanes from the
+//   chunk whenever `refill` of them have finished: a long traversal in one
+//   lane does not idle the other 63, and there is a single drain per wave.
+// * Traversal is split into node steps (two f32 slab tests on one 64-byte
+//   record) and leaf steps (the reference's f64 primitive test).  A lane that
+//   reaches a leaf queues it (up to `leafq` per lane) and keeps walking; the
+//   queued tests run together once fewer than `node_min` lanes still have node
+//   work, so neither kind of step runs with most lanes masked off.  Leaf tests
+//   run in depth-first order, which is all the reference's result depends on.
+// * Per-lane stacks and leaf queues live in LDS, laid out [level][lane].
+extern __shared__ uint32_t g_lds[];
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) k_extend(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits,
-                                                 unsigned long long *visit_counters) {
-  uint32_t n = *count_ptr;
-  uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
-  uint32_t *stack = g_stack + threadIdx.x;
+constexpr uint32_t kClaim = 256;
+constexpr uint32_t kNoRay = 0xffffffffu;
+
+struct ExtendTuning {
+  int refill;    // refill idle lanes when at least this many are idle
+  int node_min;  // run the queued leaf tests when fewer lanes than this have node work
+  int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
+};
+
+template <bool QUIRK, bool COUNT>
+__global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
+                                                ExtendTuning tune, unsigned long long *visit_counters) {
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int stride = 64;
+  uint32_t *stack = g_lds + lane;
+  uint32_t *leafq = g_lds + (size_t)sc.stack_depth * 64 + lane;
+  const uint32_t home = blockIdx.x % kRegions;
+  uint32_t region_try = 0;         // regions tried so far (wave-uniform)
+  uint32_t w_next = 0, w_end = 0;  // the wave's claimed range of queue entries (wave-uniform)
+  bool dry = false;                // every region is exhausted (wave-uniform)
+
+  uint32_t j = kNoRay;
+  d3 ro = D3(0, 0, 0), rd = D3(0, 0, 1);
+  RayF f = {};
+  Traversal tv;
+  trav_begin(sc, tv);
+  tv.cur = kDone;
   uint32_t nn = 0, nl = 0;
-  for (uint32_t j = lb * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    Ray r = make_ray_normalized(D3(q.ox[j], q.oy[j], q.oz[j]), D3(q.dx[j], q.dy[j], q.dz[j]));
-    Hit h = bvh_closest_hit<COUNT>(sc, r, stack, (int)blockDim.x, &nn, &nl);
-    hits.t[j] = h.t;
-    hits.ref[j] = h.ref;
+
+  for (;;) {
+    // ---------------------------------------------------------------- refill
+    unsigned long long idle = __ballot(j == kNoRay);
+    int n_idle = __popcll(idle);
+    if (!dry && n_idle >= tune.refill) {
+      while (w_next >= w_end && !dry) {  // claim a new chunk: own region first, then the others
+        uint32_t r = (home + region_try) % kRegions;
+        uint32_t r_count = counts[r * kCounterStride];
+        uint32_t off = r_count;
+        if (*(volatile uint32_t *)&work[r * kCounterStride] < r_count) {
+          if (lane == 0) off = atomicAdd(&work[r * kCounterStride], kClaim);
+          off = __shfl(off, 0);
+        }
+        if (off < r_count) {
+          w_next = r * q.cap + off;
+          w_end = r * q.cap + min(off + kClaim, r_count);
+        } else if (++region_try == kRegions) {
+          dry = true;
+        }
+      }
+      if (w_next < w_end) {
+        uint32_t cand = w_next + (uint32_t)__popcll(idle & lt_mask);
+        if (j == kNoRay && cand < w_end) {
+          j = cand;
+          ro = D3(q.ox[j], q.oy[j], q.oz[j]);
+          rd = D3(q.dx[j], q.dy[j], q.dz[j]);
+          f = make_rayf(ro, rd);
+          trav_begin(sc, tv);
+        }
+        w_next = min(w_end, w_next + (uint32_t)n_idle);
+        n_idle = __popcll(__ballot(j == kNoRay));
+      }
+    }
+    if (n_idle == 64) {
+      if (dry) break;
+      continue;  // nothing in flight yet: claim again
+    }
+    // ------------------------------------------------------------- node step
+    if (!(tv.cur & kRefLeaf)) {
+      if (COUNT) nn++;
+      trav_node<QUIRK>(sc, f, tv, stack, stride);
+    }
+    // a lane that now holds a leaf queues it and moves on
+    if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
+    // ------------------------------------------------------------ leaf phase
+    int node_lanes = __popcll(__ballot(!(tv.cur & kRefLeaf)));
+    if (node_lanes < tune.node_min && __ballot(tv.qn > 0)) {
+      for (int k = 0; k < kMaxLeafQueue; k++) {
+        if (!__ballot(k < tv.qn)) break;
+        if (k < tv.qn) {
+          if (COUNT) nl++;
+          int height = 64;
+          if (QUIRK) height = k == 0 ? tv.m01.x : k == 1 ? tv.m01.y : k == 2 ? tv.m23.x : tv.m23.y;
+          trav_test_leaf<QUIRK>(sc, ro, rd, tv, leafq[k * stride], height);
+        }
+      }
+      tv.qn = 0;
+      if (QUIRK && tv.cur == kWait) trav_pop<QUIRK>(tv, stack, stride);
+    }
+    // ---------------------------------------------------------------- retire
+    if (tv.cur == kDone && tv.qn == 0 && j != kNoRay) {
+      hits.t[j] = tv.best.t;
+      hits.ref[j] = tv.best.ref;
+      j = kNoRay;
+    }
   }
   if (COUNT) {
     atomicAdd(&visit_counters[0], (unsigned long long)nn);
     atomicAdd(&visit_counters[1], (unsigned long long)nl);
+  }
+}
+
+static ExtendTuning extend_tuning() {
+  ExtendTuning t{24, 32, kMaxLeafQueue};
+  if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
+  if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
+  if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
+  return t;
+}
+
+static size_t extend_lds_bytes(const DevScene &sc) { return (size_t)(sc.stack_depth + kMaxLeafQueue) * 64 * sizeof(uint32_t); }
+
+// `counts` = entries per region, `work` = claim counters per region (zeroed by the caller); both
+// kCounterStride words apart.
+static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t n_upper, hipStream_t st, PathQueue q,
+                          const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
+  static const ExtendTuning tune = extend_tuning();
+  // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
+  // a whole number of them per region
+  int64_t claims = (n_upper + kClaim - 1) / kClaim;
+  int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, 256 * 32));
+  dim3 g(grid), b(64);
+  size_t lds = extend_lds_bytes(sc);
+  if (quirk) {
+    if (counted) hipLaunchKernelGGL((k_extend<true, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    else hipLaunchKernelGGL((k_extend<true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+  } else {
+    if (counted) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    else hipLaunchKernelGGL((k_extend<false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
   }
 }
 
@@ -160,7 +319,7 @@ __global__ void __launch_bounds__(256) k_extend(DevScene sc, PathQueue q, const 
 __device__ double attractor_pdf_value(const DevScene &sc, d3 origin, d3 direction) {
   double weight = 1.0 / (double)sc.n_attractors;
   double sum = 0.0;
-  Ray probe = make_ray(origin, direction);  // Ray::new re-normalises
+  Ray probe = {origin, normalized(direction), D3(0, 0, 0)};  // Ray::new re-normalises; the tests below never read inv
   for (int a = 0; a < sc.n_attractors; a++) {
     uint32_t ref = sc.attractors[a];
     uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
@@ -217,137 +376,163 @@ RT_DEV double cosine_pdf_value(const Onb &uvw, d3 direction) {  // pdf.rs:159-16
   return fmax(0.0, cosine_theta / kPi);
 }
 
+// Per-path results, written once when the path ends: radiance (RGB, 24
+// contiguous bytes) and the number of BVH queries the path made.
+struct PathResults {
+  double *radiance;
+  uint16_t *n_rays;
+};
+
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
-                                                uint32_t *out_count, double *radiance, int32_t n_slots, int32_t S, int32_t last_bounce,
-                                                int32_t flags) {
-  uint32_t n = *count_ptr;
-  uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
-  uint32_t stride = gridDim.x * blockDim.x;
+                                                uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
+  // workgroup b serves region b % kRegions (gridDim is a multiple of kRegions)
+  const uint32_t region = blockIdx.x % kRegions;
+  const uint32_t n = count_ptr[region * kCounterStride];
+  const uint32_t stride = (gridDim.x / kRegions) * blockDim.x;
   // round the trip count up to whole waves so every lane reaches the ballot
-  uint32_t n_round = (n + 63u) & ~63u;
-  int64_t plane = (int64_t)n_slots * S;  // radiance is stored as 3 planes
-  for (uint32_t j = lb * blockDim.x + threadIdx.x; j < n_round; j += stride) {
+  const uint32_t n_round = (n + 63u) & ~63u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t in0 = region * q.cap, out0 = region * out.cap;
+  uint32_t *out_counter = out_count + region * kCounterStride;
+  for (uint32_t jj = (blockIdx.x / kRegions) * blockDim.x + threadIdx.x; jj < n_round; jj += stride) {
+    const uint32_t j = in0 + jj;
+    // ---- phase A: load, classify, decide whether the path goes on
     bool alive = false;
-    d3 no = D3(0, 0, 0), nd = D3(0, 0, 0), T = D3(0, 0, 0);
+    int32_t mkind = -1;
+    bool front_face = false;
+    d3 normal = D3(0, 0, 1), albedo = D3(0, 0, 0), point = D3(0, 0, 0), d = D3(0, 0, 1), T = D3(0, 0, 0);
+    d3 nd = D3(0, 0, 0), rad = D3(0.0, 0.0, 0.0);
+    double param = 0.0;
     uint64_t rng = 0;
     uint32_t pid = 0;
-    if (j < n) {
-      pid = q.pid[j];
-      T = D3(q.tx[j], q.ty[j], q.tz[j]);
+    if (jj < n) {
+      // every load of the path state is issued before the first use
       uint32_t ref = hits.ref[j];
-      d3 rad = D3(0.0, 0.0, 0.0);
-      if (ref != kRefNone) {
-        double t = hits.t[j];
-        d3 o = D3(q.ox[j], q.oy[j], q.oz[j]), d = D3(q.dx[j], q.dy[j], q.dz[j]);
-        rng = q.rng[j];
-        d3 point = o + d * t;  // Ray::at
+      double t = hits.t[j];
+      pid = q.pid[j];
+      rng = q.rng[j];
+      T = D3(q.tx[j], q.ty[j], q.tz[j]);
+      d3 o = D3(q.ox[j], q.oy[j], q.oz[j]);
+      d = D3(q.dx[j], q.dy[j], q.dz[j]);
+      bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
+      if (ref != kRefNone && !dead_weight) {
+        point = o + d * t;  // Ray::at
         uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
-        d3 normal;
-        uint32_t mat;
-        bool front_face;
-        if (kind == RT_PRIM_TRIANGLE) {
-          normal = ld3(sc.tri_normals + 3 * (size_t)idx);
-          mat = sc.triangles[idx].material;
+        if (kind == RT_PRIM_TRIANGLE) {  // one 64-byte record: normal + material
+          const double2 *p = reinterpret_cast<const double2 *>(&sc.tri_shade[idx]);
+          double2 a = p[0], b = p[1], c = p[2], e = p[3];
+          normal = D3(a.x, a.y, b.x);
+          albedo = D3(b.y, c.x, c.y);
+          param = e.x;
+          mkind = (int32_t)(__double_as_longlong(e.y) & 0xffffffffll);
           front_face = dot(d, normal) < 0.0;
-        } else if (kind == RT_PRIM_QUAD) {
-          normal = ld3(sc.quads[idx].normal);
-          mat = sc.quads[idx].material;
-          front_face = dot(d, normal) < 0.0;
-        } else {  // sphere.rs:127-136
-          const DevSphere &s = sc.spheres[idx];
-          d3 outward = normalized((point - ld3(s.center)) / s.radius);
-          front_face = dot(d, outward) < 0.0;
-          normal = front_face ? outward : neg(outward);
-          mat = s.material;
+        } else {
+          uint32_t mat;
+          if (kind == RT_PRIM_QUAD) {
+            normal = ld3(sc.quads[idx].normal);
+            mat = sc.quads[idx].material;
+            front_face = dot(d, normal) < 0.0;
+          } else {  // sphere.rs:127-136
+            const DevSphere &sp = sc.spheres[idx];
+            d3 outward = normalized((point - ld3(sp.center)) / sp.radius);
+            front_face = dot(d, outward) < 0.0;
+            normal = front_face ? outward : neg(outward);
+            mat = sp.material;
+          }
+          const DevMaterial &m = sc.materials[mat];
+          albedo = ld3(m.albedo);
+          param = m.param;
+          mkind = m.kind;
         }
-        const DevMaterial &m = sc.materials[mat];
-        d3 albedo = ld3(m.albedo);
-        if (m.kind == RT_MAT_DIFFUSE_LIGHT) {
+        if (mkind == RT_MAT_DIFFUSE_LIGHT) {
           if (front_face) rad = T * albedo;  // diffuse_light.rs:20-29
         } else if (last_bounce) {
           // the next ray_color call would run at depth 0 and return black
-        } else if (m.kind == RT_MAT_LAMBERTIAN) {
-          Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
-          d3 dir;
-          double pdf_val, spdf;
-          if (sc.n_attractors > 0) {  // integrator.rs:381-391, MixedPDF ratio 0.5
-            double pick = rng_gen_range(rng, 0.0, 1.0);
-            if (pick < 0.5) dir = attractor_generate(sc, point, rng);
-            else dir = onb_local_vec(uvw, random_cosine_direction(rng));
-            nd = normalized(dir);
-            spdf = cosine_pdf_value(uvw, nd);
-            pdf_val = 0.5 * attractor_pdf_value(sc, point, nd) + (1. - 0.5) * spdf;
-          } else {
-            dir = onb_local_vec(uvw, random_cosine_direction(rng));
-            nd = normalized(dir);
-            spdf = cosine_pdf_value(uvw, nd);
-            pdf_val = spdf;
-          }
-          // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419)
-          d3 Tn = ((T * albedo) * spdf) / pdf_val;
-          if (has_nan(Tn)) Tn = D3(0., 0., 0.);
-          bool zero = (Tn.x == 0.0 && Tn.y == 0.0 && Tn.z == 0.0);
-          if (!(zero && (flags & kFlagEarlyTerminate))) {
-            T = Tn;
-            no = point;
-            alive = true;
-          }
-        } else if (m.kind == RT_MAT_METAL) {  // metal.rs:21-53
+        } else if (mkind == RT_MAT_METAL) {  // metal.rs:21-53
           d3 v = normalized(d);
           d3 reflected = v - normal * (2.0 * dot(v, normal));
-          d3 dir = reflected + random_unit_vector(rng) * m.param;
+          d3 dir = reflected + random_unit_vector(rng) * param;
           if (dot(normal, dir) > 0.0) {
             T = albedo * T;
-            no = point;
             nd = normalized(dir);
             alive = true;
           }
-        } else {  // dielectric.rs:24-66
-          double ratio = front_face ? 1.0 / m.param : m.param;
-          d3 unit_direction = normalized(d);
-          d3 minus = unit_direction * -1.0;
-          double cos_theta = fmin(dot(normal, minus), 1.0);
-          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-          bool cannot_refract = ratio * sin_theta > 1.0;
-          bool reflect = cannot_refract;
-          if (!reflect) {  // the draw happens only when refraction is possible
-            double r0 = (1.0 - ratio) / (1.0 + ratio);
-            r0 = r0 * r0;
-            double x1 = 1.0 - cos_theta, x2 = x1 * x1;
-            double refl = r0 + (1.0 - r0) * (x2 * x2 * x1);
-            reflect = refl > rng_gen_f64(rng);
-          }
-          d3 dir;
-          if (reflect) {
-            dir = unit_direction - normal * (2.0 * dot(unit_direction, normal));
-          } else {  // refract_ray, metal.rs:62-68
-            double ct = fmin(dot(normal, unit_direction * -1.0), 1.0);
-            d3 r_out_perp = (unit_direction + normal * ct) * ratio;
-            d3 r_out_parallel = normal * (sqrt(fabs(1.0 - length_squared(r_out_perp))) * -1.0);
-            dir = r_out_perp + r_out_parallel;
-          }
-          no = point;
-          nd = normalized(dir);
-          alive = true;  // attenuation is white
+        } else {
+          alive = true;  // Lambertian and Dielectric always continue
         }
       }
-      if (!alive) {
-        radiance[pid] = rad.x;
-        radiance[plane + pid] = rad.y;
-        radiance[2 * plane + pid] = rad.z;
-      }
     }
-    // wave64 stream compaction: ballot, prefix popcount, one atomic per wave
+    // ---- wave64 stream compaction: ballot, prefix popcount, one atomic per wave.  The atomic
+    // is issued here and its result is not needed before the stores at the end, so its
+    // round trip overlaps the sampling arithmetic below.
     unsigned long long mask = __ballot(alive);
+    uint32_t base = 0;
+    int leader = mask ? __ffsll((long long)mask) - 1 : 0;
+    if (mask && (int)lane == leader) base = atomicAdd(out_counter, (uint32_t)__popcll(mask));
+
+    // ---- phase B: sample the next direction
+    if (alive && mkind == RT_MAT_LAMBERTIAN) {
+      Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
+      d3 dir;
+      double pdf_val, spdf;
+      if (sc.n_attractors > 0) {  // integrator.rs:381-391, MixedPDF ratio 0.5
+        double pick = rng_gen_range(rng, 0.0, 1.0);
+        if (pick < 0.5) dir = attractor_generate(sc, point, rng);
+        else dir = onb_local_vec(uvw, random_cosine_direction(rng));
+        nd = normalized(dir);
+        spdf = cosine_pdf_value(uvw, nd);
+        pdf_val = 0.5 * attractor_pdf_value(sc, point, nd) + (1. - 0.5) * spdf;
+      } else {
+        dir = onb_local_vec(uvw, random_cosine_direction(rng));
+        nd = normalized(dir);
+        spdf = cosine_pdf_value(uvw, nd);
+        pdf_val = spdf;
+      }
+      // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419).
+      // A zero throughput keeps the path going exactly as the reference keeps tracing it;
+      // with RT_FLAG_EARLY_TERMINATE the next bounce drops it.
+      d3 Tn = ((T * albedo) * spdf) / pdf_val;
+      if (has_nan(Tn)) Tn = D3(0., 0., 0.);
+      T = Tn;
+    } else if (alive && mkind == RT_MAT_DIELECTRIC) {  // dielectric.rs:24-66
+      double ratio = front_face ? 1.0 / param : param;
+      d3 unit_direction = normalized(d);
+      d3 minus = unit_direction * -1.0;
+      double cos_theta = fmin(dot(normal, minus), 1.0);
+      double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+      bool cannot_refract = ratio * sin_theta > 1.0;
+      bool reflect = cannot_refract;
+      if (!reflect) {  // the draw happens only when refraction is possible
+        double r0 = (1.0 - ratio) / (1.0 + ratio);
+        r0 = r0 * r0;
+        double x1 = 1.0 - cos_theta, x2 = x1 * x1;
+        double refl = r0 + (1.0 - r0) * (x2 * x2 * x1);
+        reflect = refl > rng_gen_f64(rng);
+      }
+      d3 dir;
+      if (reflect) {
+        dir = unit_direction - normal * (2.0 * dot(unit_direction, normal));
+      } else {  // refract_ray, metal.rs:62-68
+        double ct = fmin(dot(normal, unit_direction * -1.0), 1.0);
+        d3 r_out_perp = (unit_direction + normal * ct) * ratio;
+        d3 r_out_parallel = normal * (sqrt(fabs(1.0 - length_squared(r_out_perp))) * -1.0);
+        dir = r_out_perp + r_out_parallel;
+      }
+      nd = normalized(dir);  // attenuation is white
+    }
+
+    // ---- phase C: stores
+    if (jj < n && !alive) {
+      res.radiance[3 * (size_t)pid + 0] = rad.x;
+      res.radiance[3 * (size_t)pid + 1] = rad.y;
+      res.radiance[3 * (size_t)pid + 2] = rad.z;
+      res.n_rays[pid] = (uint16_t)(bounce + 1);
+    }
     if (mask) {
-      uint32_t lane = threadIdx.x & 63u;
-      uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      uint32_t base = 0;
-      if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(out_count, (uint32_t)__popcll(mask));
-      base = __shfl(base, __ffsll((long long)mask) - 1);
+      base = __shfl(base, leader);
       if (alive) {
-        uint32_t k = base + prefix;
-        out.ox[k] = no.x; out.oy[k] = no.y; out.oz[k] = no.z;
+        uint32_t k = out0 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        out.ox[k] = point.x; out.oy[k] = point.y; out.oz[k] = point.z;
         out.dx[k] = nd.x; out.dy[k] = nd.y; out.dz[k] = nd.z;
         out.tx[k] = T.x; out.ty[k] = T.y; out.tz[k] = T.z;
         out.rng[k] = rng;
@@ -363,73 +548,90 @@ struct PixelOutputs {
   uint32_t *samples;
 };
 
-__global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint32_t *active, int32_t n_slots, int32_t batch,
-                                                     const double *radiance, const double *weights, double *hist, uint32_t *next_active,
-                                                     uint32_t *next_count, PixelOutputs out, const uint32_t *qcounts,
-                                                     unsigned long long *rays_by_depth) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+// One lane per active pixel.  Processes the G batches of the round in order,
+// exactly as the `'batch` loop of integrator.rs:279-328 would: ordered sum of
+// the batch, Stats::push, z-test, stop.  Batches after the stopping one were
+// traced speculatively and are ignored.  totals[0] accumulates the BVH queries
+// of the accepted samples.
+__global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint32_t *active, int32_t n_slots, int32_t batch0, int32_t G,
+                                                     PathResults res, const double *weights, double *sums, double *hist,
+                                                     uint32_t *next_active, uint32_t *next_count, PixelOutputs out, const uint32_t *qcounts,
+                                                     unsigned long long *totals) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {  // queue sizes = queries traced per bounce (first wave)
     for (int k = 0; k < rp.max_depth; k++) {
-      int slot = k < RT_MAX_DEPTH_STATS ? k : RT_MAX_DEPTH_STATS - 1;
-      rays_by_depth[slot] += qcounts[k];
+      unsigned long long c = 0;
+      for (int r = threadIdx.x; r < kRegions; r += 64) c += qcounts[((size_t)k * kRegions + r) * kCounterStride];
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+      if (threadIdx.x == 0) totals[1 + (k < RT_MAX_DEPTH_STATS ? k : RT_MAX_DEPTH_STATS - 1)] += c;
     }
   }
   int32_t n_round = (n_slots + 63) & ~63;
-  int64_t plane = (int64_t)n_slots * rp.S;
   size_t np = (size_t)rp.n_pix;
+  const uint32_t lane = threadIdx.x & 63u;
   for (int32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
     bool again = false;
     uint32_t p = 0;
+    unsigned long long my_rays = 0, my_samples = 0;
     if (slot < n_slots) {
       p = active[slot];
-      // integrator.rs:280-317: batch_color += ray_color * w, in sample order
-      double br = 0.0, bg = 0.0, bb = 0.0, bw = 0.0;
-      for (int i = 0; i < rp.S; i++) {
-        int64_t pid = (int64_t)i * n_slots + slot;
-        double w = weights[pid];
-        br = br + radiance[pid] * w;
-        bg = bg + radiance[plane + pid] * w;
-        bb = bb + radiance[2 * plane + pid] * w;
-        bw += w;
+      double *ps = sums + p;
+      double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0;
+      if (batch0) {
+        sr = ps[0]; sg = ps[np]; sb = ps[2 * np]; sw = ps[3 * np];
       }
-      // stats.push(batch_color / batch_sum_sample_weight, batch_sum_sample_weight)
-      double *h = hist + (size_t)batch * 4 * np + p;
-      h[0] = br / bw;
-      h[np] = bg / bw;
-      h[2 * np] = bb / bw;
-      h[3 * np] = bw;
-      int nb = batch + 1;
-      // Stats::mean, stats.rs:21-30
-      double mr = 0.0, mg = 0.0, mb = 0.0, sw = 0.0;
-      for (int k = 0; k < nb; k++) {
-        const double *hk = hist + (size_t)k * 4 * np + p;
-        double w = hk[3 * np];
-        mr = mr + hk[0] * w;
-        mg = mg + hk[np] * w;
-        mb = mb + hk[2 * np] * w;
-      }
-      for (int k = 0; k < nb; k++) sw += hist[(size_t)k * 4 * np + 3 * np + p];
-      mr = mr / sw;
-      mg = mg / sw;
-      mb = mb / sw;
-      bool stop = false;
-      if (batch > rp.min_batches) {  // integrator.rs:321-326
-        double variance = 0.0;      // Stats::variance, stats.rs:32-47
-        if (nb != 1) {
-          double mean_l = (mr + mr + mb + mg + mg + mg) / 6.0;
-          double nominator = 0.0;
-          for (int k = 0; k < nb; k++) {
-            const double *hk = hist + (size_t)k * 4 * np + p;
-            double r = hk[0], g = hk[np], b = hk[2 * np];
-            double dl = (r + r + b + g + g + g) / 6.0 - mean_l;
-            nominator += hk[3 * np] * (dl * dl);
-          }
-          variance = nominator / sw;
+      bool done = false;
+      double mr = 0.0, mg = 0.0, mb = 0.0;
+      int nb = batch0;
+      for (int g = 0; g < G && !done; g++) {
+        int batch = batch0 + g;
+        // integrator.rs:280-317: batch_color += ray_color * w, in sample order
+        double br = 0.0, bg = 0.0, bb = 0.0, bw = 0.0;
+        size_t first = ((size_t)slot * G + g) * rp.S;
+        for (int i = 0; i < rp.S; i++) {
+          size_t pid = first + i;
+          double w = weights[pid];
+          br = br + res.radiance[3 * pid + 0] * w;
+          bg = bg + res.radiance[3 * pid + 1] * w;
+          bb = bb + res.radiance[3 * pid + 2] * w;
+          bw += w;
+          my_rays += res.n_rays[pid];
         }
-        double interval = 1.96 * (sqrt(variance) / sqrt((double)nb));
-        double illum = 0.2126 * mr + 0.7152 * mg + 0.0722 * mb;
-        stop = interval < 0.05 * illum;
+        // stats.push(batch_color / batch_sum_sample_weight, batch_sum_sample_weight)
+        double cr = br / bw, cg = bg / bw, cb = bb / bw;
+        nb = batch + 1;
+        // Stats::mean (stats.rs:21-30) folds colors[k] * weights[k] and weights[k] from zero in
+        // push order; keeping the two partial folds per pixel and adding this batch's term
+        // performs exactly the same additions in the same order.
+        sr = sr + cr * bw;
+        sg = sg + cg * bw;
+        sb = sb + cb * bw;
+        sw += bw;
+        mr = sr / sw; mg = sg / sw; mb = sb / sw;
+        // the variance needs every batch again (the mean moved): keep its illuminance_approx and weight
+        if (hist) {
+          hist[(size_t)batch * 2 * np + p] = (cr + cr + cb + cg + cg + cg) / 6.0;
+          hist[(size_t)batch * 2 * np + np + p] = bw;
+        }
+        bool stop = false;
+        if (batch > rp.min_batches) {  // integrator.rs:321-326
+          double variance = 0.0;      // Stats::variance, stats.rs:32-47
+          if (nb != 1) {
+            double mean_l = (mr + mr + mb + mg + mg + mg) / 6.0;
+            double nominator = 0.0;
+            for (int k = 0; k < nb; k++) {
+              double dl = hist[(size_t)k * 2 * np + p] - mean_l;
+              nominator += hist[(size_t)k * 2 * np + np + p] * (dl * dl);
+            }
+            variance = nominator / sw;
+          }
+          double interval = 1.96 * (sqrt(variance) / sqrt((double)nb));
+          double illum = 0.2126 * mr + 0.7152 * mg + 0.0722 * mb;
+          stop = interval < 0.05 * illum;
+        }
+        done = stop || batch == rp.max_batches - 1;
       }
-      if (stop || batch == rp.max_batches - 1) {
+      my_samples = (unsigned long long)(nb - batch0) * (unsigned long long)rp.S;
+      if (done) {
         // integrator.rs:331: mean.clamp().linear_to_gamma(gamma)
         double inv_g = 1.0 / rp.gamma;
         out.pixels[3 * (size_t)p + 0] = pow(fmax(fmin(mr, 1.0), 0.0), inv_g);
@@ -450,12 +652,21 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
         }
         if (out.samples) out.samples[p] = (uint32_t)actual;
       } else {
+        ps[0] = sr; ps[np] = sg; ps[2 * np] = sb; ps[3 * np] = sw;
         again = true;
       }
     }
+    // BVH queries of the accepted samples: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+      my_rays += __shfl_down(my_rays, off);
+      my_samples += __shfl_down(my_samples, off);
+    }
+    if (lane == 0 && my_samples) {
+      atomicAdd(&totals[0], my_rays);
+      atomicAdd(&totals[RT_MAX_DEPTH_STATS + 3], my_samples);
+    }
     unsigned long long mask = __ballot(again);
     if (mask) {
-      uint32_t lane = threadIdx.x & 63u;
       int leader = __ffsll((long long)mask) - 1;
       uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       uint32_t base = 0;
@@ -471,6 +682,7 @@ __global__ void k_iota(uint32_t *a, uint32_t n) {
 }
 
 // ============================================== primary hits / caller rays
+// Both entry points write a ray queue and run the production k_extend on it.
 RT_DEV int32_t element_of(const DevScene &sc, uint32_t ref) {
   if (ref == kRefNone) return -1;
   uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
@@ -479,10 +691,10 @@ RT_DEV int32_t element_of(const DevScene &sc, uint32_t ref) {
   return (int32_t)sc.spheres[idx].element;
 }
 
-__global__ void __launch_bounds__(256) k_primary(DevScene sc, RenderParams rp, int32_t *prim_id, double *t_out) {
+__global__ void __launch_bounds__(256) k_primary_rays(DevScene sc, RenderParams rp, PathQueue q, uint32_t *counts) {
   int64_t n = (int64_t)rp.n_pix * rp.S;
-  uint32_t *stack = g_stack + threadIdx.x;
-  uint32_t nn = 0, nl = 0;
+  const uint32_t share = region_share(n);
+  if (blockIdx.x == 0) region_publish_counts(n, share, counts);
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     int32_t p = (int32_t)(j / rp.S), i = (int32_t)(j % rp.S);
     int32_t x = p % rp.width;
@@ -499,22 +711,31 @@ __global__ void __launch_bounds__(256) k_primary(DevScene sc, RenderParams rp, i
     }
     d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
     d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
-    Ray r = make_ray(origin, pixel_sample - origin);
-    Hit h = bvh_closest_hit<false>(sc, r, stack, (int)blockDim.x, &nn, &nl);
-    prim_id[j] = element_of(sc, h.ref);
-    t_out[j] = (h.ref == kRefNone) ? 0.0 : h.t;
+    d3 dir = normalized(pixel_sample - origin);
+    uint32_t e = region_place(j, share, q.cap);
+    q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+    q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
   }
 }
 
-__global__ void __launch_bounds__(256) k_trace(DevScene sc, int64_t n, const double *origins, const double *directions,
-                                                int32_t *prim_id, double *t_out) {
-  uint32_t *stack = g_stack + threadIdx.x;
-  uint32_t nn = 0, nl = 0;
+__global__ void __launch_bounds__(256) k_caller_rays(int64_t n, const double *origins, const double *directions, PathQueue q, uint32_t *counts) {
+  const uint32_t share = region_share(n);
+  if (blockIdx.x == 0) region_publish_counts(n, share, counts);
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    Ray r = make_ray(ld3(origins + 3 * j), ld3(directions + 3 * j));
-    Hit h = bvh_closest_hit<false>(sc, r, stack, (int)blockDim.x, &nn, &nl);
-    prim_id[j] = element_of(sc, h.ref);
-    t_out[j] = (h.ref == kRefNone) ? 0.0 : h.t;
+    d3 dir = normalized(ld3(directions + 3 * j));  // Ray::new, ray.rs:35-48
+    uint32_t e = region_place(j, share, q.cap);
+    q.ox[e] = origins[3 * j]; q.oy[e] = origins[3 * j + 1]; q.oz[e] = origins[3 * j + 2];
+    q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_hits_to_elements(DevScene sc, int64_t n, uint32_t cap, HitBuffer hits, int32_t *prim_id, double *t_out) {
+  const uint32_t share = region_share(n);
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t e = region_place(j, share, cap);
+    uint32_t ref = hits.ref[e];
+    prim_id[j] = element_of(sc, ref);
+    t_out[j] = (ref == kRefNone) ? 0.0 : hits.t[e];
   }
 }
 
@@ -626,7 +847,9 @@ int grid_for(int64_t n, int block, int max_blocks) {
   return (int)g;
 }
 
-size_t stack_bytes(const RtSceneHandle *h, int block) { return (size_t)std::max(h->dev.stack_depth, 1) * (size_t)block * sizeof(uint32_t); }
+// Children whose box the ray misses are skipped whenever that cannot change a result (every box
+// bounds its contents); otherwise, or on request, the reference's visit rule is followed exactly.
+bool use_quirk(const RtSceneHandle *h, int32_t flags) { return h->dev.quirk || (flags & kFlagReferenceVisitRule); }
 
 }  // namespace
 
@@ -707,6 +930,68 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   }
   if (max_depth > kMaxStackDepth) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than 64 levels");
 
+  // Does every child box contain the primitives below it?  (The reference's
+  // quad box, quad.rs:86, does not for quads that are not axis-aligned.)  If
+  // not, k_extend must reproduce the reference's irregular visit rule.
+  bool boxes_bound_contents = true;
+  {
+    struct B { double mn[3], mx[3]; };
+    std::vector<B> sub((size_t)s->n_nodes);
+    auto grow = [](B &b, double x, double y, double z) {
+      const double p[3] = {x, y, z};
+      for (int a = 0; a < 3; a++) {
+        if (!(p[a] >= b.mn[a])) b.mn[a] = p[a] != p[a] ? -INFINITY : p[a];
+        if (!(p[a] <= b.mx[a])) b.mx[a] = p[a] != p[a] ? INFINITY : p[a];
+      }
+    };
+    auto inside = [](const B &b, const double *mn, const double *mx) {
+      for (int a = 0; a < 3; a++)
+        if (!(mn[a] <= b.mn[a] && b.mx[a] <= mx[a])) return false;
+      return true;
+    };
+    for (int i = s->n_nodes - 1; i >= 0; i--) {
+      const RtNode &n = s->nodes[i];
+      B &b = sub[(size_t)i];
+      for (int a = 0; a < 3; a++) b.mn[a] = INFINITY, b.mx[a] = -INFINITY;
+      if (n.is_leaf) {
+        RtElementRef e = s->elements[n.element_index];
+        if (e.kind == RT_PRIM_TRIANGLE) {
+          const RtTriangle &t = s->triangles[e.index];
+          grow(b, t.v0.x, t.v0.y, t.v0.z);
+          grow(b, t.v0.x + t.v0v1.x, t.v0.y + t.v0v1.y, t.v0.z + t.v0v1.z);
+          grow(b, t.v0.x + t.v0v2.x, t.v0.y + t.v0v2.y, t.v0.z + t.v0v2.z);
+        } else if (e.kind == RT_PRIM_QUAD) {
+          const RtQuad &qd = s->quads[e.index];
+          for (int cu = 0; cu < 2; cu++)
+            for (int cv = 0; cv < 2; cv++)
+              grow(b, qd.q.x + cu * qd.u.x + cv * qd.v.x, qd.q.y + cu * qd.u.y + cv * qd.v.y, qd.q.z + cu * qd.u.z + cv * qd.v.z);
+        } else {
+          const RtSphere &sp = s->spheres[e.index];
+          double rad = std::fabs(sp.radius);
+          grow(b, sp.center.x - rad, sp.center.y - rad, sp.center.z - rad);
+          grow(b, sp.center.x + rad, sp.center.y + rad, sp.center.z + rad);
+        }
+      } else {
+        const B &l = sub[(size_t)n.child_l_index], &r = sub[(size_t)n.child_r_index];
+        // triangle corners are re-derived from v0 + edge, which can round one ulp past the stored box
+        auto slack = [](const B &x) {
+          B y = x;
+          for (int a = 0; a < 3; a++) {
+            double m = std::fmax(std::fabs(y.mn[a]), std::fabs(y.mx[a])) * 4.5e-16;
+            y.mn[a] += m;
+            y.mx[a] -= m;
+          }
+          return y;
+        };
+        if (!inside(slack(l), n.child_l_min, n.child_l_max) || !inside(slack(r), n.child_r_min, n.child_r_max)) boxes_bound_contents = false;
+        for (int a = 0; a < 3; a++) {
+          b.mn[a] = std::fmin(l.mn[a], r.mn[a]);
+          b.mx[a] = std::fmax(l.mx[a], r.mx[a]);
+        }
+      }
+    }
+  }
+
   // ---- flatten
   auto ref_of_element = [&](int e) -> uint32_t {
     RtElementRef er = s->elements[e];
@@ -732,7 +1017,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     d.pad[0] = d.pad[1] = 0;
   }
   std::vector<DevTriangle> tris((size_t)s->n_triangles);
-  std::vector<double> tri_normals((size_t)s->n_triangles * 3);
+  std::vector<DevTriShade> tri_shade((size_t)s->n_triangles);
   std::vector<DevQuad> quads((size_t)s->n_quads);
   std::vector<DevSphere> spheres((size_t)s->n_spheres);
   for (int e = 0; e < s->n_elements; e++) {
@@ -745,9 +1030,13 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.e2[0] = t.v0v2.x; d.e2[1] = t.v0v2.y; d.e2[2] = t.v0v2.z;
       d.element = (uint32_t)e;
       d.material = (uint32_t)t.material;
-      tri_normals[3 * (size_t)er.index + 0] = t.normal.x;
-      tri_normals[3 * (size_t)er.index + 1] = t.normal.y;
-      tri_normals[3 * (size_t)er.index + 2] = t.normal.z;
+      DevTriShade &sh = tri_shade[(size_t)er.index];
+      const RtMaterial &m = s->materials[t.material];
+      sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
+      sh.albedo[0] = m.albedo[0]; sh.albedo[1] = m.albedo[1]; sh.albedo[2] = m.albedo[2];
+      sh.param = m.param;
+      sh.kind = m.kind;
+      sh.pad = 0;
     } else if (er.kind == RT_PRIM_QUAD) {
       const RtQuad &q = s->quads[er.index];
       DevQuad &d = quads[(size_t)er.index];
@@ -797,7 +1086,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   };
   step(dev_upload(h, &h->dev.nodes, nodes));
   step(dev_upload(h, &h->dev.triangles, tris));
-  step(dev_upload(h, &h->dev.tri_normals, tri_normals));
+  step(dev_upload(h, &h->dev.tri_shade, tri_shade));
   step(dev_upload(h, &h->dev.quads, quads));
   step(dev_upload(h, &h->dev.spheres, spheres));
   step(dev_upload(h, &h->dev.materials, mats));
@@ -812,6 +1101,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   h->dev.n_attractors = s->n_attractors;
   h->dev.root = ref_of_node(0);
   h->dev.stack_depth = std::max(max_depth, 1);
+  h->dev.quirk = boxes_bound_contents ? 0 : 1;
   h->dev.camera = s->camera;
   *out = h;
   return RT_OK;
@@ -832,41 +1122,67 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   const bool counted = (rp.flags & kFlagCountVisits) != 0;
   auto wall0 = std::chrono::steady_clock::now();
 
-  // paths per chunk: bounded so the SoA queues stay a few GB
-  int64_t max_paths = 1ll << 24;
+  // Paths per round.  A round traces G consecutive batches of every active pixel at once (the
+  // batches after a pixel's stopping batch are speculative and dropped by k_accumulate), which
+  // keeps launches large late in a render; HBM is big enough for >100 M paths in flight.
+  const int64_t bytes_per_path = 2 * (9 * 8 + 8 + 4) + (8 + 4) + 3 * 8 + 8 + 2;
+  int64_t max_paths = 1ll << 27;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_paths = std::min<int64_t>(max_paths, (int64_t)(free_b / 2) / bytes_per_path);
+  }
   if (const char *env = getenv("RT_HIP_MAX_PATHS")) {
     long long v = atoll(env);
-    if (v >= 64) max_paths = v;
+    if (v >= 1) max_paths = v;
   }
-  int32_t chunk_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(n_pix, max_paths / S));
-  int64_t chunk_paths = (int64_t)chunk_slots * S;
-  if (chunk_paths > 0xfffffff0ll) return fail(RT_ERR_UNSUPPORTED, "sample_batch_size too large for one chunk");
+  int max_group = 16;
+  if (const char *env = getenv("RT_HIP_MAX_GROUP")) max_group = std::max(1, atoi(env));
+  max_paths = std::max<int64_t>(max_paths, S);
+  max_paths = std::min<int64_t>(max_paths, 0xfffffff0ll / 3);
+  const int64_t cap_paths = std::min<int64_t>(max_paths / S * S, (int64_t)n_pix * S * std::min(rp.max_batches, max_group));
+  if (S > cap_paths) return fail(RT_ERR_UNSUPPORTED, "sample_batch_size too large for one round");
 
   Scratch sc;
+  // queue entries per region (whole waves) and in total
+  const uint32_t region_cap = (uint32_t)(((cap_paths + kRegions - 1) / kRegions + 63) / 64 * 64);
+  const size_t q_entries = (size_t)region_cap * kRegions;
   PathQueue q[2];
   for (int k = 0; k < 2; k++) {
-    HIP_TRY(sc.alloc(&q[k].ox, chunk_paths)); HIP_TRY(sc.alloc(&q[k].oy, chunk_paths)); HIP_TRY(sc.alloc(&q[k].oz, chunk_paths));
-    HIP_TRY(sc.alloc(&q[k].dx, chunk_paths)); HIP_TRY(sc.alloc(&q[k].dy, chunk_paths)); HIP_TRY(sc.alloc(&q[k].dz, chunk_paths));
-    HIP_TRY(sc.alloc(&q[k].tx, chunk_paths)); HIP_TRY(sc.alloc(&q[k].ty, chunk_paths)); HIP_TRY(sc.alloc(&q[k].tz, chunk_paths));
-    HIP_TRY(sc.alloc(&q[k].rng, chunk_paths));
-    HIP_TRY(sc.alloc(&q[k].pid, chunk_paths));
+    HIP_TRY(sc.alloc(&q[k].ox, q_entries)); HIP_TRY(sc.alloc(&q[k].oy, q_entries)); HIP_TRY(sc.alloc(&q[k].oz, q_entries));
+    HIP_TRY(sc.alloc(&q[k].dx, q_entries)); HIP_TRY(sc.alloc(&q[k].dy, q_entries)); HIP_TRY(sc.alloc(&q[k].dz, q_entries));
+    HIP_TRY(sc.alloc(&q[k].tx, q_entries)); HIP_TRY(sc.alloc(&q[k].ty, q_entries)); HIP_TRY(sc.alloc(&q[k].tz, q_entries));
+    HIP_TRY(sc.alloc(&q[k].rng, q_entries));
+    HIP_TRY(sc.alloc(&q[k].pid, q_entries));
+    q[k].cap = region_cap;
   }
   HitBuffer hits;
-  HIP_TRY(sc.alloc(&hits.t, chunk_paths));
-  HIP_TRY(sc.alloc(&hits.ref, chunk_paths));
-  double *radiance, *weights, *hist;
-  HIP_TRY(sc.alloc(&radiance, 3 * chunk_paths));
-  HIP_TRY(sc.alloc(&weights, chunk_paths));
-  HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 4 * (size_t)n_pix));
+  HIP_TRY(sc.alloc(&hits.t, q_entries));
+  HIP_TRY(sc.alloc(&hits.ref, q_entries));
+  PathResults results;
+  double *weights, *sums, *hist = nullptr;
+  HIP_TRY(sc.alloc(&results.radiance, 3 * cap_paths));
+  HIP_TRY(sc.alloc(&results.n_rays, cap_paths));
+  HIP_TRY(sc.alloc(&weights, cap_paths));
+  HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
+  // per-batch (illuminance_approx, weight) history, needed only if the z-test can ever run
+  if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)n_pix));
   uint32_t *active[2], *counters;
   HIP_TRY(sc.alloc(&active[0], n_pix));
   HIP_TRY(sc.alloc(&active[1], n_pix));
-  // counters: [0] next_count, [1 .. max_depth+1] queue sizes per bounce
-  const int n_counters = rp.max_depth + 2;
+  // counters (each on its own 128-byte line): [0] next_count; then per bounce 0..max_depth the
+  // kRegions queue sizes; then per bounce the kRegions work-claim counters of k_extend
+  const size_t per_bounce = (size_t)kRegions * kCounterStride;
+  const size_t n_counters = kCounterStride + (size_t)(2 * rp.max_depth + 1) * per_bounce;
   HIP_TRY(sc.alloc(&counters, n_counters));
-  unsigned long long *totals;  // [0..15] rays by depth, [16] node visits, [17] leaf tests
-  HIP_TRY(sc.alloc(&totals, RT_MAX_DEPTH_STATS + 2));
-  HIP_TRY(hipMemsetAsync(totals, 0, (RT_MAX_DEPTH_STATS + 2) * sizeof(unsigned long long), st));
+  uint32_t *qcounts = counters + kCounterStride;
+  uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
+  const bool quirk = use_quirk(h, rp.flags);
+  // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
+  // [18] leaf tests, [19] accepted samples
+  constexpr int kTotals = RT_MAX_DEPTH_STATS + 4;
+  unsigned long long *totals;
+  HIP_TRY(sc.alloc(&totals, kTotals));
+  HIP_TRY(hipMemsetAsync(totals, 0, kTotals * sizeof(unsigned long long), st));
 
   PixelOutputs po{};
   if (out->memory == RT_MEM_DEVICE) {
@@ -883,18 +1199,19 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
 
   const int block = 256;
   const int max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups
-  size_t lds = stack_bytes(h, block);
   hipLaunchKernelGGL(k_iota, dim3(grid_for(n_pix, block, max_blocks)), dim3(block), 0, st, active[0], (uint32_t)n_pix);
 
   struct TimedLaunch {
     hipEvent_t a, b;
     int kind;  // 0 extend, 1 shade, 2 other
+    int depth;
   };
   std::vector<TimedLaunch> timeline;
-  auto mark_begin = [&](int kind) -> hipError_t {
+  auto mark_begin = [&](int kind, int depth = 0) -> hipError_t {
     if (!timed) return hipSuccess;
     TimedLaunch t{};
     t.kind = kind;
+    t.depth = depth;
     hipError_t e = hipEventCreate(&t.a);
     if (e != hipSuccess) return e;
     sc.events.push_back(t.a);
@@ -908,43 +1225,63 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
 
   uint32_t n_active = (uint32_t)n_pix;
   int cur = 0;
-  uint64_t batches = 0, samples = 0;
-  for (int b = 0; b < rp.max_batches && n_active > 0; b++) {
+  uint64_t rounds = 0;
+  int b = 0;
+  int group = 1;
+  while (b < rp.max_batches && n_active > 0) {
+    // how many batches this round traces at once
+    int G;
+    if (b == 0) {
+      // no pixel can stop before batch min+1 (integrator.rs:321): those batches are never speculative
+      G = std::min(rp.max_batches, rp.min_batches + 2);
+    } else {
+      G = std::min(group, rp.max_batches - b);
+    }
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, cap_paths / ((int64_t)n_active * S)));
+    // if even one batch of every active pixel exceeds the buffers, walk the pixels in chunks
+    const uint32_t chunk_slots = (uint32_t)std::min<int64_t>(n_active, cap_paths / ((int64_t)S * G));
     HIP_TRY(hipMemsetAsync(counters, 0, sizeof(uint32_t), st));
-    for (uint32_t base = 0; base < n_active; base += (uint32_t)chunk_slots) {
-      int32_t ns = (int32_t)std::min<uint32_t>((uint32_t)chunk_slots, n_active - base);
-      int64_t np = (int64_t)ns * S;
-      HIP_TRY(hipMemsetAsync(counters + 1, 0, (size_t)(rp.max_depth + 1) * sizeof(uint32_t), st));
+    for (uint32_t base = 0; base < n_active; base += chunk_slots) {
+      int32_t ns = (int32_t)std::min<uint32_t>(chunk_slots, n_active - base);
+      int64_t np = (int64_t)ns * S * G;
+      HIP_TRY(hipMemsetAsync(qcounts, 0, (n_counters - kCounterStride) * sizeof(uint32_t), st));
       int g = grid_for(np, block, max_blocks);
+      int g_shade = std::max(kRegions, g / kRegions * kRegions);
       HIP_TRY(mark_begin(2));
-      hipLaunchKernelGGL(k_generate, dim3(g), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, q[0], weights, counters + 1);
+      hipLaunchKernelGGL(k_generate, dim3(g), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
-        HIP_TRY(mark_begin(0));
-        if (counted)
-          hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(block), lds, st, h->dev, q[k & 1], counters + 1 + k, hits, totals + RT_MAX_DEPTH_STATS);
-        else
-          hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(block), lds, st, h->dev, q[k & 1], counters + 1 + k, hits, totals + RT_MAX_DEPTH_STATS);
+        HIP_TRY(mark_begin(0, k));
+        launch_extend(h->dev, quirk, counted, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, totals + RT_MAX_DEPTH_STATS + 1);
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1));
-        hipLaunchKernelGGL(k_shade, dim3(g), dim3(block), 0, st, h->dev, q[k & 1], counters + 1 + k, hits, q[(k + 1) & 1], counters + 2 + k,
-                           radiance, ns, S, (int32_t)(k == rp.max_depth - 1), rp.flags);
+        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
+                           results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
         HIP_TRY(mark_end());
       }
       HIP_TRY(mark_begin(2));
-      if (rp.max_depth == 0) HIP_TRY(hipMemsetAsync(radiance, 0, 3 * (size_t)np * sizeof(double), st));
-      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ns, block, max_blocks)), dim3(block), 0, st, rp, active[cur] + base, ns, b, radiance, weights,
-                         hist, active[cur ^ 1], counters, po, counters + 1, totals);
+      if (rp.max_depth == 0) {
+        HIP_TRY(hipMemsetAsync(results.radiance, 0, 3 * (size_t)np * sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(results.n_rays, 0, (size_t)np * sizeof(uint16_t), st));
+      }
+      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ns, block, max_blocks)), dim3(block), 0, st, rp, active[cur] + base, ns, b, G, results, weights,
+                         sums, hist, active[cur ^ 1], counters, po, qcounts, totals);
       HIP_TRY(mark_end());
-      samples += (uint64_t)np;
     }
     HIP_TRY(hipGetLastError());
     uint32_t next = 0;
     HIP_TRY(hipMemcpyAsync(&next, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    // speculate further ahead while (almost) no pixel stops, back off when many do
+    uint32_t stopped = n_active - next;
+    if (b + G < rp.max_batches) {
+      if ((uint64_t)stopped * 50 <= n_active) group = std::min(max_group, std::max(1, group * 2));
+      else group = std::max(1, group / 2);
+    }
     n_active = next;
     cur ^= 1;
-    batches++;
+    b += G;
+    rounds++;
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
@@ -957,23 +1294,27 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   }
   if (stats) {
     memset(stats, 0, sizeof *stats);
-    unsigned long long host_totals[RT_MAX_DEPTH_STATS + 2];
+    unsigned long long host_totals[kTotals];
     HIP_TRY(hipMemcpy(host_totals, totals, sizeof host_totals, hipMemcpyDeviceToHost));
+    stats->rays = host_totals[0];
     for (int k = 0; k < RT_MAX_DEPTH_STATS; k++) {
-      stats->rays_by_depth[k] = host_totals[k];
-      stats->rays += host_totals[k];
+      stats->rays_by_depth[k] = host_totals[1 + k];
+      stats->rays_traced += host_totals[1 + k];
     }
-    stats->node_visits = host_totals[RT_MAX_DEPTH_STATS];
-    stats->leaf_tests = host_totals[RT_MAX_DEPTH_STATS + 1];
+    stats->node_visits = host_totals[RT_MAX_DEPTH_STATS + 1];
+    stats->leaf_tests = host_totals[RT_MAX_DEPTH_STATS + 2];
     stats->box_tests = 2 * stats->node_visits;
-    stats->samples = samples;
-    stats->batches = batches;
+    stats->samples = host_totals[RT_MAX_DEPTH_STATS + 3];
+    stats->batches = rounds;
     for (const TimedLaunch &t : timeline) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
       if (t.kind == 0) {
         stats->trace_kernel_ms += ms;
         stats->trace_launches++;
+        stats->trace_ms_by_depth[t.depth < RT_MAX_DEPTH_STATS ? t.depth : RT_MAX_DEPTH_STATS - 1] += ms;
+      } else if (t.kind == 1) {
+        stats->shade_kernel_ms += ms;
       } else {
         stats->other_kernel_ms += ms;
       }
@@ -994,6 +1335,40 @@ int rt_hip_render(const RtScene *scene, const RtConfig *cfg, RtImage *out, RtSta
   return rc;
 }
 
+static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, uint32_t *d_counts, int32_t flags, int32_t *prim_id, double *t) {
+  const size_t entries = (size_t)q.cap * kRegions;
+  HitBuffer hits;
+  int32_t *d_id;
+  double *d_t;
+  HIP_TRY(sc.alloc(&hits.t, entries));
+  HIP_TRY(sc.alloc(&hits.ref, entries));
+  HIP_TRY(sc.alloc(&d_id, (size_t)n));
+  HIP_TRY(sc.alloc(&d_t, (size_t)n));
+  const int block = 256;
+  uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
+  launch_extend(h->dev, use_quirk(h, flags), false, n, h->stream, q, d_counts, hits, work, nullptr);
+  hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(prim_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+// Ray-only queue (origin + direction) for n rays, plus its region counts and claim counters (zeroed).
+static int alloc_ray_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue *q, uint32_t **d_counts) {
+  if (n > 0xfffffff0ll / 2) return fail(RT_ERR_UNSUPPORTED, "more than 2^31 rays in one call");
+  memset(q, 0, sizeof *q);
+  q->cap = (uint32_t)(((n + kRegions - 1) / kRegions + 63) / 64 * 64);
+  const size_t entries = (size_t)q->cap * kRegions;
+  HIP_TRY(sc.alloc(&q->ox, entries)); HIP_TRY(sc.alloc(&q->oy, entries)); HIP_TRY(sc.alloc(&q->oz, entries));
+  HIP_TRY(sc.alloc(&q->dx, entries)); HIP_TRY(sc.alloc(&q->dy, entries)); HIP_TRY(sc.alloc(&q->dz, entries));
+  const size_t words = 2 * (size_t)kRegions * kCounterStride;
+  HIP_TRY(sc.alloc(d_counts, words));
+  HIP_TRY(hipMemsetAsync(*d_counts, 0, words * sizeof(uint32_t), h->stream));
+  return RT_OK;
+}
+
 int rt_hip_primary_hits(RtSceneHandle *h, const RtConfig *cfg, int32_t *prim_id, double *t) {
   g_error.clear();
   if (!h || !prim_id || !t) return fail(RT_ERR_BAD_ARG, "NULL argument");
@@ -1003,17 +1378,12 @@ int rt_hip_primary_hits(RtSceneHandle *h, const RtConfig *cfg, int32_t *prim_id,
   RenderParams rp = make_params(cfg);
   int64_t n = (int64_t)rp.n_pix * rp.S;
   Scratch sc;
-  int32_t *d_id;
-  double *d_t;
-  HIP_TRY(sc.alloc(&d_id, (size_t)n));
-  HIP_TRY(sc.alloc(&d_t, (size_t)n));
-  const int block = 256;
-  hipLaunchKernelGGL(k_primary, dim3(grid_for(n, block, 2048)), dim3(block), stack_bytes(h, block), h->stream, h->dev, rp, d_id, d_t);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(prim_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(t, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  return RT_OK;
+  PathQueue q;
+  uint32_t *d_count;
+  rc = alloc_ray_queue(h, sc, n, &q, &d_count);
+  if (rc != RT_OK) return rc;
+  hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, rp, q, d_count);
+  return trace_queue(h, sc, n, q, d_count, cfg->flags, prim_id, t);
 }
 
 int rt_hip_trace_rays(RtSceneHandle *h, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
@@ -1022,19 +1392,15 @@ int rt_hip_trace_rays(RtSceneHandle *h, int64_t n, const double *origins, const 
   if (n == 0) return RT_OK;
   HIP_TRY(hipSetDevice(h->device));
   Scratch sc;
-  double *d_o, *d_d, *d_t;
-  int32_t *d_id;
+  double *d_o, *d_d;
   HIP_TRY(sc.alloc(&d_o, 3 * (size_t)n));
   HIP_TRY(sc.alloc(&d_d, 3 * (size_t)n));
-  HIP_TRY(sc.alloc(&d_t, (size_t)n));
-  HIP_TRY(sc.alloc(&d_id, (size_t)n));
   HIP_TRY(hipMemcpy(d_o, origins, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_d, directions, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-  const int block = 256;
-  hipLaunchKernelGGL(k_trace, dim3(grid_for(n, block, 2048)), dim3(block), stack_bytes(h, block), h->stream, h->dev, n, d_o, d_d, d_id, d_t);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(prim_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(t, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  return RT_OK;
+  PathQueue q;
+  uint32_t *d_count;
+  int rc = alloc_ray_queue(h, sc, n, &q, &d_count);
+  if (rc != RT_OK) return rc;
+  hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_o, d_d, q, d_count);
+  return trace_queue(h, sc, n, q, d_count, 0, prim_id, t);
 }
