@@ -15,6 +15,7 @@ def c1(width=48, height=48, batch=8, max_batches=1, min_batches=1, defocus=0.0, 
 
 def knot_scene(directory, n_triangles, width, height, batch, max_batches, min_batches, split="SAH", defocus=0.0):
     """C3-like scene with a small generated mesh."""
+    os.makedirs(directory, exist_ok=True)
     obj = os.path.join(directory, f"knot_{n_triangles}.obj")
     if not os.path.exists(obj):
         v, f = scenes.knot_mesh(n_triangles)
