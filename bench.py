@@ -27,6 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 NODE_BYTES = 64        # device BVH node: two f32 child boxes + two refs
 TRI_BYTES = 80         # device triangle record: v0, e1, e2 (f64) + ids
 RAY_STATE_BYTES = 48 + 12  # k_extend reads origin + direction (6 f64), writes t + ref
+# HBM/fabric bytes per ray of k_extend measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
+# on this same workload; produced by tools/summarize_profiles.py from separate counter runs.
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")
 
 
 def main():
@@ -176,6 +179,14 @@ def main():
         # per-GPU figures for the dominant kernel (k_extend): this rank's rays over this rank's kernel time
         achieved = (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         value = rays_all / elapsed / 1e6
+        traffic = traffic_note = None
+        if os.path.exists(TRAFFIC_JSON) and args.triangles == 100_000 and (W, H) == (1200, 1200) and not opt_flags:
+            with open(TRAFFIC_JSON) as fh:
+                tj = json.load(fh)
+            if tj.get("hbm_bytes_per_ray"):
+                traffic = tj["hbm_bytes_per_ray"] * rays / max(launches, 1)  # bytes per launch
+                traffic_note = (f"{tj['hbm_bytes_per_ray']:.1f} B/ray from PMC passes (profiles/r01_traffic.json) "
+                                f"x {rays / max(launches, 1):.0f} rays per launch")
         line = {
             "metric": "Mrays/s",
             "value": value,
@@ -210,7 +221,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": rays * bytes_per_ray / max(launches, 1),
                 "bytes_per_ray": bytes_per_ray,
                 "node_visits_per_ray": v_int,
                 "leaf_tests_per_ray": v_leaf,
