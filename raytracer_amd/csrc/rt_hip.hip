@@ -122,7 +122,10 @@ __device__ __forceinline__ uint32_t xcd_logical_block(uint32_t b, uint32_t nbloc
 // ================================================================== generate
 // One lane per (active pixel slot, batch g of the group, sample i); the path
 // id is (slot * G + g) * S + i, so the samples of one batch of one pixel are
-// adjacent (coherent primary rays, contiguous per-path outputs).
+// adjacent: coherent primary rays, and paths that end at the same bounce store
+// neighbouring result records.  The Sobol index restarts with every
+// batch (integrator.rs:285), so the filter weight of sample i of a pixel is the
+// same in every batch: it is stored once, by batch 0, as weights[i * n_pix + p].
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
                                                    int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
   int64_t n = (int64_t)n_slots * G * rp.S;
@@ -156,10 +159,10 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     uint32_t e = region_place(j, share, q.cap);
     q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
     q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
-    q.tx[e] = 1.0; q.ty[e] = 1.0; q.tz[e] = 1.0;
+    // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
     q.rng[e] = rng;
     q.pid[e] = (uint32_t)j;
-    weights[j] = w;
+    if (batch0 + g == 0) weights[(size_t)i * (size_t)rp.n_pix + p] = w;
   }
 }
 
@@ -380,11 +383,15 @@ RT_DEV double cosine_pdf_value(const Onb &uvw, d3 direction) {  // pdf.rs:159-16
   return fmax(0.0, cosine_theta / kPi);
 }
 
-// Per-path results, written once when the path ends: radiance (RGB, 24
-// contiguous bytes) and the number of BVH queries the path made.
+// Per-path result, written once when the path ends: one aligned 32-byte record
+// (a single sector for the scattered store) holding the radiance and the
+// number of BVH queries the path made.
+struct alignas(32) PathRecord {
+  double r, g, b;
+  uint64_t n_rays;
+};
 struct PathResults {
-  double *radiance;
-  uint16_t *n_rays;
+  PathRecord *rec;
 };
 
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       double t = hits.t[j];
       pid = q.pid[j];
       rng = q.rng[j];
-      T = D3(q.tx[j], q.ty[j], q.tz[j]);
+      T = bounce ? D3(q.tx[j], q.ty[j], q.tz[j]) : D3(1.0, 1.0, 1.0);
       d3 o = D3(q.ox[j], q.oy[j], q.oz[j]);
       d = D3(q.dx[j], q.dy[j], q.dz[j]);
       bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
@@ -527,10 +534,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
 
     // ---- phase C: stores
     if (jj < n && !alive) {
-      res.radiance[3 * (size_t)pid + 0] = rad.x;
-      res.radiance[3 * (size_t)pid + 1] = rad.y;
-      res.radiance[3 * (size_t)pid + 2] = rad.z;
-      res.n_rays[pid] = (uint16_t)(bounce + 1);
+      double4 rec = {rad.x, rad.y, rad.z, __longlong_as_double((long long)(bounce + 1))};
+      double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
+      dst[0] = make_double2(rec.x, rec.y);
+      dst[1] = make_double2(rec.z, rec.w);
     }
     if (mask) {
       base = __shfl(base, leader);
@@ -551,6 +558,7 @@ struct PixelOutputs {
   double *pixels, *sample_pixels, *linear;
   uint32_t *samples;
 };
+constexpr int kAccChunk = 8;  // batches k_accumulate evaluates together
 
 // One lane per active pixel.  Processes the G batches of the round in order,
 // exactly as the `'batch` loop of integrator.rs:279-328 would: ordered sum of
@@ -572,92 +580,166 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
   int32_t n_round = (n_slots + 63) & ~63;
   size_t np = (size_t)rp.n_pix;
   const uint32_t lane = threadIdx.x & 63u;
+  // per-wave staging tile: 64 slots x 128 bytes, rows padded to 144 bytes against bank conflicts
+  __shared__ double2 tile_all[4][64 * 9];
+  double2 *tile = tile_all[threadIdx.x >> 6];
   for (int32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
     bool again = false;
     uint32_t p = 0;
     unsigned long long my_rays = 0, my_samples = 0;
-    if (slot < n_slots) {
+    const bool valid = slot < n_slots;
+    const int32_t slot0 = slot - (int32_t)lane;  // first slot of this wave
+    double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0;
+    double *ps = sums;
+    if (valid) {
       p = active[slot];
-      double *ps = sums + p;
-      double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0;
+      ps = sums + p;
       if (batch0) {
         sr = ps[0]; sg = ps[np]; sb = ps[2 * np]; sw = ps[3 * np];
       }
-      bool done = false;
-      double mr = 0.0, mg = 0.0, mb = 0.0;
-      int nb = batch0;
-      for (int g = 0; g < G && !done; g++) {
-        int batch = batch0 + g;
-        // integrator.rs:280-317: batch_color += ray_color * w, in sample order
-        double br = 0.0, bg = 0.0, bb = 0.0, bw = 0.0;
-        size_t first = ((size_t)slot * G + g) * rp.S;
-        int i = 0;
-        // four samples at a time: 16 independent loads in flight, then the ordered adds
-        for (; i + 4 <= rp.S; i += 4) {
-          const double *rr = res.radiance + 3 * (first + i);
-          const double *ww = weights + first + i;
-          const uint16_t *nn = res.n_rays + first + i;
-          double r[12], w[4];
-          uint32_t nr[4];
+    }
+    bool done = !valid;
+    double mr = 0.0, mg = 0.0, mb = 0.0;
+    int nb = batch0;
+    const double *ww = weights + p;
+    // The batches of the round are handled kAccChunk at a time, in three passes that together
+    // perform, per pixel, exactly the operations of the reference's batch loop in its order:
+    //   1. per batch: the ordered sum of its samples, Stats::push, the running mean;
+    //   2. Stats::variance for all batches of the chunk at once -- every history entry is
+    //      loaded once and folded into each batch's own nominator (each fold still runs over
+    //      k = 0..nb-1 in order with that batch's mean);
+    //   3. the z-test decisions in batch order; batches after a pixel's stopping batch were
+    //      speculative and leave no trace.
+    for (int g0 = 0; g0 < G; g0 += kAccChunk) {
+      const unsigned long long busy = __ballot(!done);
+      if (!busy) break;
+      const int gc = G - g0 < kAccChunk ? G - g0 : kAccChunk;
+      const int kb = batch0 + g0;  // first batch of the chunk = number of history entries before it
+      double mrv[kAccChunk], mgv[kAccChunk], mbv[kAccChunk], swv[kAccChunk], nom[kAccChunk];
+      uint32_t rays_v[kAccChunk];
+      // ---- pass 1
 #pragma unroll
-          for (int k = 0; k < 12; k++) r[k] = rr[k];
+      for (int gi = 0; gi < kAccChunk; gi++) {
+        mrv[gi] = mgv[gi] = mbv[gi] = swv[gi] = nom[gi] = 0.0;
+        rays_v[gi] = 0;
+        if (gi < gc) {
+          const int g = g0 + gi;
+          // integrator.rs:280-317: batch_color += ray_color * w, in sample order
+          double br = 0.0, bg = 0.0, bb = 0.0, bw = 0.0;
+          uint32_t nr = 0;
+          for (int i0 = 0; i0 < rp.S; i0 += 4) {
+            const int nrec = rp.S - i0 < 4 ? rp.S - i0 : 4;
+            // The 4 records of one slot are 128 contiguous bytes.  Load instruction k fetches those
+            // of slots 8k..8k+7, 16 bytes per lane (whole lines, each fetched once), and the tile in
+            // LDS hands every lane the records of its own slot.
+            double2 v[8];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            w[k] = ww[k];
-            nr[k] = nn[k];
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            br = br + r[3 * k + 0] * w[k];
-            bg = bg + r[3 * k + 1] * w[k];
-            bb = bb + r[3 * k + 2] * w[k];
-            bw += w[k];
-            my_rays += nr[k];
-          }
-        }
-        for (; i < rp.S; i++) {
-          size_t pid = first + i;
-          double w = weights[pid];
-          br = br + res.radiance[3 * pid + 0] * w;
-          bg = bg + res.radiance[3 * pid + 1] * w;
-          bb = bb + res.radiance[3 * pid + 2] * w;
-          bw += w;
-          my_rays += res.n_rays[pid];
-        }
-        // stats.push(batch_color / batch_sum_sample_weight, batch_sum_sample_weight)
-        double cr = br / bw, cg = bg / bw, cb = bb / bw;
-        nb = batch + 1;
-        // Stats::mean (stats.rs:21-30) folds colors[k] * weights[k] and weights[k] from zero in
-        // push order; keeping the two partial folds per pixel and adding this batch's term
-        // performs exactly the same additions in the same order.
-        sr = sr + cr * bw;
-        sg = sg + cg * bw;
-        sb = sb + cb * bw;
-        sw += bw;
-        mr = sr / sw; mg = sg / sw; mb = sb / sw;
-        // the variance needs every batch again (the mean moved): keep its illuminance_approx and weight
-        if (hist) {
-          hist[(size_t)batch * 2 * np + p] = (cr + cr + cb + cg + cg + cg) / 6.0;
-          hist[(size_t)batch * 2 * np + np + p] = bw;
-        }
-        bool stop = false;
-        if (batch > rp.min_batches) {  // integrator.rs:321-326
-          double variance = 0.0;      // Stats::variance, stats.rs:32-47
-          if (nb != 1) {
-            double mean_l = (mr + mr + mb + mg + mg + mg) / 6.0;
-            double nominator = 0.0;
-            for (int k = 0; k < nb; k++) {
-              double dl = hist[(size_t)k * 2 * np + p] - mean_l;
-              nominator += hist[(size_t)k * 2 * np + np + p] * (dl * dl);
+            for (int k = 0; k < 8; k++) {
+              const int sl = 8 * k + (int)(lane >> 3), piece = (int)(lane & 7u);
+              v[k] = make_double2(0.0, 0.0);
+              if (((busy >> sl) & 1ull) && piece < 2 * nrec)
+                v[k] = reinterpret_cast<const double2 *>(res.rec + ((size_t)(slot0 + sl) * G + g) * rp.S + i0)[piece];
             }
-            variance = nominator / sw;
+#pragma unroll
+            for (int k = 0; k < 8; k++) tile[(8 * k + (lane >> 3)) * 9 + (lane & 7u)] = v[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double2 m[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) m[k] = tile[lane * 9 + k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!done) {
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                if (k < nrec) {
+                  double w = ww[(size_t)(i0 + k) * np];
+                  br = br + m[2 * k].x * w;
+                  bg = bg + m[2 * k].y * w;
+                  bb = bb + m[2 * k + 1].x * w;
+                  bw += w;
+                  nr += (uint32_t)__double_as_longlong(m[2 * k + 1].y);
+                }
+              }
+            }
           }
-          double interval = 1.96 * (sqrt(variance) / sqrt((double)nb));
-          double illum = 0.2126 * mr + 0.7152 * mg + 0.0722 * mb;
-          stop = interval < 0.05 * illum;
+          if (!done) {
+            // stats.push(batch_color / batch_sum_sample_weight, batch_sum_sample_weight)
+            double cr = br / bw, cg = bg / bw, cb = bb / bw;
+            // Stats::mean (stats.rs:21-30) folds colors[k] * weights[k] and weights[k] from zero in
+            // push order; keeping the two partial folds per pixel and adding this batch's term
+            // performs exactly the same additions in the same order.
+            sr = sr + cr * bw;
+            sg = sg + cg * bw;
+            sb = sb + cb * bw;
+            sw += bw;
+            mrv[gi] = sr / sw; mgv[gi] = sg / sw; mbv[gi] = sb / sw;
+            swv[gi] = sw;
+            rays_v[gi] = nr;
+            // the variance needs every batch again (the mean moved): keep its illuminance_approx and weight
+            if (hist) {
+              hist[(size_t)(kb + gi) * 2 * np + p] = (cr + cr + cb + cg + cg + cg) / 6.0;
+              hist[(size_t)(kb + gi) * 2 * np + np + p] = bw;
+            }
+          }
         }
-        done = stop || batch == rp.max_batches - 1;
       }
+      // ---- pass 2: Stats::variance nominators (stats.rs:32-47); only batches > min_batches are ever tested
+      if (hist && !done && kb + gc - 1 > rp.min_batches) {
+        double ml[kAccChunk];
+#pragma unroll
+        for (int gi = 0; gi < kAccChunk; gi++) ml[gi] = (mrv[gi] + mrv[gi] + mbv[gi] + mgv[gi] + mgv[gi] + mgv[gi]) / 6.0;
+        const double *hp = hist + p;
+        int k = 0;
+        for (; k + 4 <= kb; k += 4) {  // entries every batch of the chunk folds
+          double hl[4], hw[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            hl[u] = hp[(size_t)(k + u) * 2 * np];
+            hw[u] = hp[(size_t)(k + u) * 2 * np + np];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int gi = 0; gi < kAccChunk; gi++) {
+              double dl = hl[u] - ml[gi];
+              nom[gi] += hw[u] * (dl * dl);
+            }
+          }
+        }
+        for (; k < kb + gc; k++) {  // the rest, and the chunk's own entries: batch gi folds entries 0..kb+gi
+          double hl = hp[(size_t)k * 2 * np], hw = hp[(size_t)k * 2 * np + np];
+#pragma unroll
+          for (int gi = 0; gi < kAccChunk; gi++) {
+            if (k <= kb + gi) {
+              double dl = hl - ml[gi];
+              nom[gi] += hw * (dl * dl);
+            }
+          }
+        }
+      }
+      // ---- pass 3
+#pragma unroll
+      for (int gi = 0; gi < kAccChunk; gi++) {
+        if (gi < gc && !done) {
+          const int batch = kb + gi;
+          nb = batch + 1;
+          mr = mrv[gi]; mg = mgv[gi]; mb = mbv[gi];
+          my_rays += rays_v[gi];
+          bool stop = false;
+          if (batch > rp.min_batches) {  // integrator.rs:321-326
+            double variance = nb != 1 ? nom[gi] / swv[gi] : 0.0;
+            double interval = 1.96 * (sqrt(variance) / sqrt((double)nb));
+            double illum = 0.2126 * mr + 0.7152 * mg + 0.0722 * mb;
+            stop = interval < 0.05 * illum;
+          }
+          done = stop || batch == rp.max_batches - 1;
+        }
+      }
+    }
+    if (valid) {
+      // here `done` means the pixel is finished (it was forced on for lanes without a slot only)
       my_samples = (unsigned long long)(nb - batch0) * (unsigned long long)rp.S;
       if (done) {
         // integrator.rs:331: mean.clamp().linear_to_gamma(gamma)
@@ -1194,7 +1276,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   // Paths per round.  A round traces G consecutive batches of every active pixel at once (the
   // batches after a pixel's stopping batch are speculative and dropped by k_accumulate), which
   // keeps launches large late in a render; HBM is big enough for >100 M paths in flight.
-  const int64_t bytes_per_path = 2 * (9 * 8 + 8 + 4) + (8 + 4) + 3 * 8 + 8 + 2;
+  const int64_t bytes_per_path = 2 * (9 * 8 + 8 + 4) + (8 + 4) + (int64_t)sizeof(PathRecord);
   int64_t max_paths = 1ll << 27;
   {
     size_t free_b = 0, total_b = 0;
@@ -1229,9 +1311,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   HIP_TRY(sc.alloc(&hits.ref, q_entries));
   PathResults results;
   double *weights, *sums, *hist = nullptr;
-  HIP_TRY(sc.alloc(&results.radiance, 3 * cap_paths));
-  HIP_TRY(sc.alloc(&results.n_rays, cap_paths));
-  HIP_TRY(sc.alloc(&weights, cap_paths));
+  HIP_TRY(sc.alloc(&results.rec, cap_paths));
+  HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)n_pix));
   HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
   // per-batch (illuminance_approx, weight) history, needed only if the z-test can ever run
   if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)n_pix));
@@ -1328,8 +1409,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       }
       HIP_TRY(mark_begin(2));
       if (rp.max_depth == 0) {
-        HIP_TRY(hipMemsetAsync(results.radiance, 0, 3 * (size_t)np * sizeof(double), st));
-        HIP_TRY(hipMemsetAsync(results.n_rays, 0, (size_t)np * sizeof(uint16_t), st));
+        HIP_TRY(hipMemsetAsync(results.rec, 0, (size_t)np * sizeof(PathRecord), st));
       }
       hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ns, block, max_blocks)), dim3(block), 0, st, rp, active[cur] + base, ns, b, G, results, weights,
                          sums, hist, active[cur ^ 1], counters, po, qcounts, totals);
