@@ -135,8 +135,11 @@ def main():
     cfg_cnt = cfg.copy()
     cfg_cnt.flags = abi.RT_FLAG_COUNT_VISITS | opt_flags
     _, st_cnt = res.render(cfg_cnt, device_out=out)
-    v_int_dev = st_cnt.node_visits / max(st_cnt.rays, 1)
-    v_leaf_dev = st_cnt.leaf_tests / max(st_cnt.rays, 1)
+    v_int_dev = st_cnt.node_visits / max(st_cnt.rays_traced, 1)
+    v_leaf_dev = st_cnt.leaf_tests / max(st_cnt.rays_traced, 1)
+    # fraction of the 64 lanes doing useful work when a wave executes a node step / a leaf test
+    lanes_node = st_cnt.node_visits / max(64 * st_cnt.wave_node_steps, 1)
+    lanes_leaf = st_cnt.leaf_tests / max(64 * st_cnt.wave_leaf_steps, 1)
 
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on a bounded row sample
     cpu = None
@@ -230,6 +233,7 @@ def main():
                 "leaf_tests_per_ray": v_leaf,
                 "node_visits_per_ray_device": v_int_dev,
                 "leaf_tests_per_ray_device": v_leaf_dev,
+                "simd_lane_utilisation": {"node_steps": lanes_node, "leaf_tests": lanes_leaf},
                 "launches": launches / args.steps,
                 "avg_launch_ms": trace_ms / max(launches, 1),
                 "kernel_ms_per_step": trace_ms / args.steps,

@@ -231,6 +231,10 @@ typedef struct RtStats {
   double shade_kernel_ms;    /* sum over launches of the shading kernel */
   double other_kernel_ms;    /* generate + accumulate/z-test kernels */
   double trace_ms_by_depth[RT_MAX_DEPTH_STATS]; /* k_extend time per bounce number */
+  /* device, with RT_FLAG_COUNT_VISITS: how often a 64-lane wave executed a node step / a leaf test
+   * (64 * wave_node_steps / node_visits = average lanes idle-or-busy ratio of the SIMD) */
+  uint64_t wave_node_steps;
+  uint64_t wave_leaf_steps;
 } RtStats;
 
 typedef struct RtSceneHandle RtSceneHandle;

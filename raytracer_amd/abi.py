@@ -133,6 +133,8 @@ class RtStats(C.Structure):
         ("shade_kernel_ms", C.c_double),
         ("other_kernel_ms", C.c_double),
         ("trace_ms_by_depth", C.c_double * RT_MAX_DEPTH_STATS),
+        ("wave_node_steps", C.c_uint64),
+        ("wave_leaf_steps", C.c_uint64),
     ]
 
 

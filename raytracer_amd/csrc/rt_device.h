@@ -43,7 +43,8 @@ static_assert(sizeof(DevNode) == 64, "node must be one 64-byte record");
 // 80-byte triangle record read by the leaf test (triangle.rs:76-117).
 struct __attribute__((aligned(16))) DevTriangle {
   double v0[3], e1[3], e2[3];
-  uint32_t element, material;
+  uint32_t element;
+  uint32_t rank;  // position of the triangle's leaf in the reference's depth-first, left-first leaf order
 };
 static_assert(sizeof(DevTriangle) == 80, "triangle record");
 
@@ -61,11 +62,13 @@ struct DevQuad {
   double q[3], u[3], v[3], normal[3], w[3];
   double d, area;
   uint32_t element, material;
+  uint32_t rank, pad;
 };
 struct DevSphere {
   double center[3];
   double radius;
   uint32_t element, material;
+  uint32_t rank, pad;
 };
 struct DevMaterial {
   double albedo[3];
@@ -85,7 +88,8 @@ struct DevScene {
   int32_t n_attractors;
   uint32_t root;        // ref of nodes[0] of the reference array
   int32_t stack_depth;  // LDS stack entries per lane
-  int32_t quirk;        // 1 when some child box does not contain the primitives below it
+  int32_t quirk;        // 1 when the walk must follow the reference's visit rule step by step: some child box
+                        // does not contain the primitives below it, or the nodes do not form a tree
   RtCamera camera;
 };
 
@@ -365,6 +369,19 @@ RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, flo
   float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
   return tn <= tf * 1.000001f;
 }
+// The same test that also rejects a box lying wholly beyond `tmax` (an upper bound of the
+// closest hit so far) and reports the entry distance.  The entry distance carries the same
+// relative rounding error as the exit distance, hence the same widening of the bound.
+RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayF &f, float tmax,
+                         float &tn_out) {
+  float tlx = (bminx - f.oux) * f.ix, thx = (bmaxx - f.odx) * f.ix;
+  float tly = (bminy - f.ouy) * f.iy, thy = (bmaxy - f.ody) * f.iy;
+  float tlz = (bminz - f.ouz) * f.iz, thz = (bmaxz - f.odz) * f.iz;
+  float tn = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), 0.0f));
+  float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+  tn_out = tn;
+  return tn <= fminf(tf, tmax) * 1.000001f;
+}
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -377,6 +394,7 @@ struct Traversal {
   int qn;            // deferred leaves
   uint64_t hitmask;  // QUIRK: bit s = a hit was accepted since stack entry s was pushed
   u16x2 m01, m23;    // QUIRK: per deferred leaf, the lowest stack height since it was queued
+  float tcull;       // !QUIRK: best.t rounded up to f32 (+inf before the first hit)
   Hit best;
 };
 
@@ -387,6 +405,7 @@ RT_DEV void trav_begin(const DevScene &sc, Traversal &tv) {
   tv.hitmask = 0;
   tv.m01 = u16x2{0, 0};
   tv.m23 = u16x2{0, 0};
+  tv.tcull = INFINITY;
   tv.best.t = kF64Max;
   tv.best.ref = kRefNone;
 }
@@ -438,6 +457,25 @@ RT_DEV void trav_node(const DevScene &sc, const RayF &f, Traversal &tv, uint32_t
   const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
   float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
   uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
+  if (!QUIRK) {
+    // Boxes bound their contents: which leaves are tested, and in which order, cannot change
+    // the result (trav_test_leaf breaks ties by the reference's leaf order).  Enter the nearer
+    // child first and drop children that begin beyond the closest hit so far.
+    float tl, tr;
+    bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tv.tcull, tl);
+    bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
+    if (hl && hr) {
+      bool swap = tr < tl;
+      stack[tv.sp * stride] = swap ? left : right;
+      tv.sp++;
+      tv.cur = swap ? right : left;
+    } else if (hl || hr) {
+      tv.cur = hl ? left : right;
+    } else {
+      trav_pop<QUIRK>(tv, stack, stride);
+    }
+    return;
+  }
   bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f);
   bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f);
   if (hl) {
@@ -472,6 +510,25 @@ RT_DEV void trav_defer_leaf(Traversal &tv, const uint32_t *stack, uint32_t *leaf
   trav_pop<QUIRK>(tv, stack, stride);
 }
 
+// Two primitives hit at exactly the same t.  The reference tests leaves in depth-first,
+// left-first order and lets a later triangle/quad replace an equal hit (inclusive interval)
+// but not a later sphere (strict interval): the winner is the last triangle/quad in that
+// order if there is one, else the first sphere.  `cand` is being tested now, `best` was
+// accepted before -- in whatever order this traversal happened to reach them.
+RT_DEV uint32_t leaf_rank(const DevScene &sc, uint32_t leaf) {
+  uint32_t kind = (leaf >> kRefKindShift) & 3u, idx = leaf & kRefIndexMask;
+  if (kind == RT_PRIM_TRIANGLE) return sc.triangles[idx].rank;
+  if (kind == RT_PRIM_QUAD) return sc.quads[idx].rank;
+  return sc.spheres[idx].rank;
+}
+RT_DEV bool tie_goes_to_later_test(const DevScene &sc, uint32_t cand, uint32_t best) {
+  bool cand_sphere = ((cand >> kRefKindShift) & 3u) == RT_PRIM_SPHERE;
+  bool best_sphere = ((best >> kRefKindShift) & 3u) == RT_PRIM_SPHERE;
+  if (cand_sphere != best_sphere) return best_sphere;
+  uint32_t rc = leaf_rank(sc, cand), rb = leaf_rank(sc, best);
+  return cand_sphere ? rc < rb : rc > rb;
+}
+
 // The primitive test of the reference with the interval [kTMin, best.t]
 // (triangle/quad inclusive, sphere strict).  `height` = how many of the
 // current stack entries were already there when the leaf was reached.
@@ -488,13 +545,18 @@ RT_DEV void trav_test_leaf(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32
     ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);
   } else if (kind == RT_PRIM_QUAD) {
     ok = quad_hit(sc.quads[idx], r, kTMin, tv.best.t, t);
-  } else {
+  } else if (QUIRK) {
     ok = sphere_hit(sc.spheres[idx], r, kTMin, tv.best.t, t);
+  } else {
+    // leaves arrive out of the reference's order: let an equal t through to the tie rule below
+    ok = sphere_hit(sc.spheres[idx], r, kTMin, kF64Max, t) && t <= tv.best.t;
   }
+  if (!QUIRK && ok && t == tv.best.t && tv.best.ref != kRefNone) ok = tie_goes_to_later_test(sc, leaf, tv.best.ref);
   if (ok) {
     tv.best.t = t;
     tv.best.ref = leaf;
     if (QUIRK) tv.hitmask |= (height >= 64) ? ~0ull : ((1ull << height) - 1ull);
+    else tv.tcull = __double2float_ru(t);
   }
 }
 

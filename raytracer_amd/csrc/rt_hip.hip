@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   Traversal tv;
   trav_begin(sc, tv);
   tv.cur = kDone;
-  uint32_t nn = 0, nl = 0;
+  uint32_t nn = 0, nl = 0, wn = 0, wl = 0;  // lane and wave step counts (COUNT only)
 
   for (;;) {
     // ---------------------------------------------------------------- refill
@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     // moves on (or waits once its queue is full)
     bool pending;
     do {
+      if (COUNT) wn++;
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
         trav_node<QUIRK>(sc, f, tv, stack, stride);
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     if (pending) {
       for (int k = 0; k < kMaxLeafQueue; k++) {
         if (!__ballot(k < tv.qn)) break;
+        if (COUNT) wl++;
         if (k < tv.qn) {
           if (COUNT) nl++;
           int height = 64;
@@ -287,6 +289,10 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   if (COUNT) {
     atomicAdd(&visit_counters[0], (unsigned long long)nn);
     atomicAdd(&visit_counters[1], (unsigned long long)nl);
+    if (lane == 0) {
+      atomicAdd(&visit_counters[3], (unsigned long long)wn);
+      atomicAdd(&visit_counters[4], (unsigned long long)wl);
+    }
   }
 }
 
@@ -1143,6 +1149,33 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     }
   }
 
+  // The reference's leaf order (depth-first, left child first) decides exact ties between
+  // primitives; the reordering traversal needs it per element.  An element named by more than
+  // one reachable leaf has no single position: such a tree is walked in the reference's order.
+  std::vector<uint32_t> leaf_rank_of_element((size_t)s->n_elements, 0xffffffffu);
+  {
+    std::vector<int32_t> todo{0};
+    uint32_t next_rank = 0;
+    int64_t visited = 0;
+    while (!todo.empty()) {
+      if (++visited > (int64_t)s->n_nodes) {  // some node has two parents
+        boxes_bound_contents = false;
+        break;
+      }
+      int32_t i = todo.back();
+      todo.pop_back();
+      const RtNode &n = s->nodes[i];
+      if (n.is_leaf) {
+        uint32_t &r = leaf_rank_of_element[(size_t)n.element_index];
+        if (r != 0xffffffffu) boxes_bound_contents = false;
+        r = next_rank++;
+      } else {
+        todo.push_back(n.child_r_index);
+        todo.push_back(n.child_l_index);
+      }
+    }
+  }
+
   // ---- flatten
   auto ref_of_element = [&](int e) -> uint32_t {
     RtElementRef er = s->elements[e];
@@ -1180,7 +1213,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.e1[0] = t.v0v1.x; d.e1[1] = t.v0v1.y; d.e1[2] = t.v0v1.z;
       d.e2[0] = t.v0v2.x; d.e2[1] = t.v0v2.y; d.e2[2] = t.v0v2.z;
       d.element = (uint32_t)e;
-      d.material = (uint32_t)t.material;
+      d.rank = leaf_rank_of_element[(size_t)e];
       DevTriShade &sh = tri_shade[(size_t)er.index];
       const RtMaterial &m = s->materials[t.material];
       sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
@@ -1200,6 +1233,8 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.area = q.area;
       d.element = (uint32_t)e;
       d.material = (uint32_t)q.material;
+      d.rank = leaf_rank_of_element[(size_t)e];
+      d.pad = 0;
     } else {
       const RtSphere &sp = s->spheres[er.index];
       DevSphere &d = spheres[(size_t)er.index];
@@ -1207,6 +1242,8 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.radius = sp.radius;
       d.element = (uint32_t)e;
       d.material = (uint32_t)sp.material;
+      d.rank = leaf_rank_of_element[(size_t)e];
+      d.pad = 0;
     }
   }
   std::vector<DevMaterial> mats((size_t)s->n_materials);
@@ -1328,8 +1365,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
   const bool quirk = use_quirk(h, rp.flags);
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
-  // [18] leaf tests, [19] accepted samples
-  constexpr int kTotals = RT_MAX_DEPTH_STATS + 4;
+  // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
+  constexpr int kTotals = RT_MAX_DEPTH_STATS + 6;
   unsigned long long *totals;
   HIP_TRY(sc.alloc(&totals, kTotals));
   HIP_TRY(hipMemsetAsync(totals, 0, kTotals * sizeof(unsigned long long), st));
@@ -1452,6 +1489,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     stats->leaf_tests = host_totals[RT_MAX_DEPTH_STATS + 2];
     stats->box_tests = 2 * stats->node_visits;
     stats->samples = host_totals[RT_MAX_DEPTH_STATS + 3];
+    stats->wave_node_steps = host_totals[RT_MAX_DEPTH_STATS + 4];
+    stats->wave_leaf_steps = host_totals[RT_MAX_DEPTH_STATS + 5];
     stats->batches = rounds;
     for (const TimedLaunch &t : timeline) {
       float ms = 0.f;
