@@ -461,8 +461,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
           param = m.param;
           mkind = m.kind;
         }
+        // every material but the dielectric (white attenuation) scales the throughput by its
+        // albedo first; the product is commutative, so one multiplication serves them all
+        if (mkind != RT_MAT_DIELECTRIC) T = T * albedo;
         if (mkind == RT_MAT_DIFFUSE_LIGHT) {
-          if (front_face) rad = T * albedo;  // diffuse_light.rs:20-29
+          if (front_face) rad = T;  // diffuse_light.rs:20-29
         } else if (last_bounce) {
           // the next ray_color call would run at depth 0 and return black
         } else if (mkind == RT_MAT_METAL) {  // metal.rs:21-53
@@ -470,7 +473,6 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
           d3 reflected = v - normal * (2.0 * dot(v, normal));
           d3 dir = reflected + random_unit_vector(rng) * param;
           if (dot(normal, dir) > 0.0) {
-            T = albedo * T;
             nd = normalized(dir);
             alive = true;
           }
@@ -486,6 +488,14 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
     uint32_t base = 0;
     int leader = mask ? __ffsll((long long)mask) - 1 : 0;
     if (mask && (int)lane == leader) base = atomicAdd(out_counter, (uint32_t)__popcll(mask));
+
+    // a path that ends here stores its result now, which frees the registers for phase B
+    if (jj < n && !alive) {
+      double4 rec = {rad.x, rad.y, rad.z, __longlong_as_double((long long)(bounce + 1))};
+      double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
+      dst[0] = make_double2(rec.x, rec.y);
+      dst[1] = make_double2(rec.z, rec.w);
+    }
 
     // ---- phase B: sample the next direction
     if (alive && mkind == RT_MAT_LAMBERTIAN) {
@@ -508,7 +518,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419).
       // A zero throughput keeps the path going exactly as the reference keeps tracing it;
       // with RT_FLAG_EARLY_TERMINATE the next bounce drops it.
-      d3 Tn = ((T * albedo) * spdf) / pdf_val;
+      d3 Tn = (T * spdf) / pdf_val;  // T already holds throughput * albedo
       if (has_nan(Tn)) Tn = D3(0., 0., 0.);
       T = Tn;
     } else if (alive && mkind == RT_MAT_DIELECTRIC) {  // dielectric.rs:24-66
@@ -539,12 +549,6 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
     }
 
     // ---- phase C: stores
-    if (jj < n && !alive) {
-      double4 rec = {rad.x, rad.y, rad.z, __longlong_as_double((long long)(bounce + 1))};
-      double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
-      dst[0] = make_double2(rec.x, rec.y);
-      dst[1] = make_double2(rec.z, rec.w);
-    }
     if (mask) {
       base = __shfl(base, leader);
       if (alive) {
