@@ -236,3 +236,35 @@ def materialize_c3(directory, n_triangles=100_000, width=1200, height=1200, seed
     with open(config_path, "w") as f:
         json.dump(config_c3(width, height), f)
     return scene_path, config_path
+
+
+# --------------------------------------------------------------- triangle soup
+def soup_elements(n_triangles, seed=12345):
+    """Random triangle soup: centres uniform in the Cornell interior [20, 535]^3, edge vectors
+    uniform in [-4, 4]^3; 10 % dielectric (1.5), 10 % metal (fuzz U[0, 0.3]), 80 % Lambertian
+    (albedo U[0.2, 0.9]^3).  Winding is whatever the edges give: about half of the triangles
+    face away from any given ray and are culled (triangle.rs:88)."""
+    rng = np.random.RandomState(seed)
+    c = rng.uniform(20.0, 535.0, size=(n_triangles, 3))
+    e1 = rng.uniform(-4.0, 4.0, size=(n_triangles, 3))
+    e2 = rng.uniform(-4.0, 4.0, size=(n_triangles, 3))
+    kind = rng.uniform(size=n_triangles)
+    albedo = rng.uniform(0.2, 0.9, size=(n_triangles, 3))
+    fuzz = rng.uniform(0.0, 0.3, size=n_triangles)
+    els = []
+    for i in range(n_triangles):
+        if kind[i] < 0.1:
+            m = dielectric(1.5)
+        elif kind[i] < 0.2:
+            m = metal(albedo[i, 0], albedo[i, 1], albedo[i, 2], fuzz[i])
+        else:
+            m = lambertian(albedo[i, 0], albedo[i, 1], albedo[i, 2])
+        v0 = c[i] - (e1[i] + e2[i]) / 3.0
+        els.append({"JSONTriangle": {"v0": _v(*v0), "v1": _v(*(v0 + e1[i])), "v2": _v(*(v0 + e2[i])), "material": m}})
+    return els
+
+
+def scene_soup(n_triangles, seed=12345, defocus_angle=0.6, focus_dist=1000.0):
+    """Cornell room + quad light (attractor) filled with a triangle soup, thin-lens camera."""
+    els = soup_elements(n_triangles, seed) + cornell_elements()
+    return {"camera": camera(defocus_angle=defocus_angle, focus_dist=focus_dist), "elements": els}

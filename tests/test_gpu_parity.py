@@ -132,6 +132,73 @@ def test_rays_through_box_corners_are_never_lost():
             assert tg[i] <= to[i]
 
 
+def _tie_scene(split):
+    """Several primitives hit at exactly the same t: three copies of a triangle with different
+    materials, two copies of a sphere, a triangle lying in the plane of a quad, and a sphere
+    touching that plane, scattered among enough other triangles to spread them over the tree."""
+    from raytracer_amd import RenderIntegrator, scenes
+    els = []
+    tri = {"v0": scenes._v(200, 100, 300), "v1": scenes._v(200, 300, 300), "v2": scenes._v(400, 100, 300)}
+    quad = {"q": scenes._v(100, 50, 420), "u": scenes._v(300, 0, 0), "v": scenes._v(0, 300, 0)}
+    inplane = {"v0": scenes._v(150, 100, 420), "v1": scenes._v(150, 300, 420), "v2": scenes._v(350, 100, 420)}
+    filler = scenes.soup_elements(400, seed=3)
+    mats = [scenes.lambertian(0.9, 0.1, 0.1), scenes.metal(0.1, 0.9, 0.1, 0.0), scenes.dielectric(1.5), scenes.lambertian(0.1, 0.1, 0.9)]
+    els += filler[:100] + [{"JSONTriangle": dict(tri, material=mats[0])}]
+    els += [scenes.sphere((120, 400, 200), 50, mats[1])]
+    els += filler[100:200] + [{"JSONTriangle": dict(tri, material=mats[1])}, {"JSONQuad": dict(quad, material=mats[3])}]
+    els += filler[200:300] + [{"JSONTriangle": dict(inplane, material=mats[0])}, scenes.sphere((120, 400, 200), 50, mats[0])]
+    els += filler[300:] + [{"JSONTriangle": dict(tri, material=mats[2])}, {"JSONTriangle": dict(inplane, material=mats[1])}]
+    els += [scenes.sphere((250, 200, 370), 50, mats[2])] + scenes.cornell_elements()
+    sc = {"camera": scenes.camera(), "elements": els}
+    return RenderIntegrator.new(sc, scenes.config(32, 32, 4, 1, 1, split=split)).prepare()
+
+
+@pytest.mark.parametrize("split", ["SAH", "Mid"])
+def test_exact_ties_follow_the_reference_leaf_order(split):
+    """The device walks the tree nearest child first; among primitives hit at exactly the same
+    t it must still report the one the reference's depth-first, left-first walk ends with."""
+    ri = _tie_scene(split)
+    rng = np.random.RandomState(17)
+    n = 60_000
+    o = np.concatenate([np.tile([[278.0, 278.0, -800.0]], (n // 2, 1)), rng.uniform(30, 520, size=(n // 2, 3)) * [1, 1, 0.4]])
+    # aim at the duplicated triangle, the quad with the in-plane triangle, and the doubled sphere
+    tgt = np.concatenate([
+        np.stack([rng.uniform(190, 410, n // 3), rng.uniform(90, 310, n // 3), np.full(n // 3, 300.0)], 1),
+        np.stack([rng.uniform(90, 410, n // 3), rng.uniform(40, 360, n // 3), np.full(n // 3, 420.0)], 1),
+        np.array([120.0, 400.0, 200.0]) + rng.normal(scale=30.0, size=(n - 2 * (n // 3), 3)),
+    ])
+    rng.shuffle(tgt)
+    d = tgt - o
+    pg, tg = ri.resident(0).trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    # the test is only worth something if rays do land on the doubled primitives
+    sc = ri.scene.contents
+    kinds = np.array([sc.elements[int(e)].kind if e >= 0 else -1 for e in po])
+    assert (kinds == abi.RT_PRIM_SPHERE).sum() > 1000 and (kinds == abi.RT_PRIM_QUAD).sum() + (kinds == abi.RT_PRIM_TRIANGLE).sum() > 20000
+    assert np.array_equal(tg, to)
+    assert np.array_equal(pg, po)
+
+
+def test_soup_scene_with_glass_and_metal_triangles(tmp_scene_dir):
+    """Small version of the triangle-soup configuration: mixed materials on triangles,
+    thin-lens camera, quad-light attractor."""
+    from raytracer_amd import RenderIntegrator, scenes
+    ri = RenderIntegrator.new(scenes.scene_soup(20_000), scenes.config(40, 40, 8, 1, 1)).prepare()
+    cfg = ri.config.copy()
+    cfg.rng_mode = abi.RT_RNG_CTR
+    res = ri.resident(0)
+    pg, tg = res.primary_hits(cfg)
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+    o, d = random_rays(200_000, seed=23)
+    pg, tg = res.trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+    out_g, st_g = res.render(cfg)
+    out_o, st_o = oracle.render(ri.scene, cfg)
+    _image_checks(out_g, st_g, out_o, st_o, cfg)
+
+
 def _tilted_quad_scene():
     """A quad that is not axis-aligned: the reference boxes it by two opposite corners only
     (quad.rs:86), so parts of it stick out of its box and whether a ray finds them depends on
