@@ -85,13 +85,19 @@ def main():
         "samples": torch.empty(n_rows, W, dtype=torch.int32, device=dev),
     }
 
+    # the finished image lands in page-locked host memory on rank 0
+    if rank == 0:
+        host_img = torch.empty(H, W, 3, dtype=torch.float64, pin_memory=True)
+        host_heat = torch.empty(H, W, 3, dtype=torch.float64, pin_memory=True)
+
     def step():
         _, st = res.render(cfg, device_out=out)
         full = parallel.gather_rows(out["pixels"], H, rank, world)
         heat = parallel.gather_rows(out["sample_pixels"], H, rank, world)
         if rank == 0:
-            host_img = full.cpu()  # final f64 image on the rank-0 host
-            host_heat = heat.cpu()
+            host_img.copy_(full, non_blocking=True)  # final f64 image on the rank-0 host
+            host_heat.copy_(heat, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
             return st, host_img, host_heat
         return st, None, None
 

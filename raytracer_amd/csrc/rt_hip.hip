@@ -1327,7 +1327,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     long long v = atoll(env);
     if (v >= 1) max_paths = v;
   }
-  int max_group = 16;
+  int max_group = 32;
   if (const char *env = getenv("RT_HIP_MAX_GROUP")) max_group = std::max(1, atoi(env));
   max_paths = std::max<int64_t>(max_paths, S);
   max_paths = std::min<int64_t>(max_paths, 0xfffffff0ll / 3);
@@ -1417,6 +1417,9 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   uint64_t rounds = 0;
   int b = 0;
   int group = 1;
+  // after the first round: jump straight to this many batches if (almost) no pixel stopped in it
+  int first_jump = 8;
+  if (const char *env = getenv("RT_HIP_FIRST_GROUP")) first_jump = std::max(1, atoi(env));
   while (b < rp.max_batches && n_active > 0) {
     // how many batches this round traces at once
     int G;
@@ -1460,11 +1463,13 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     uint32_t next = 0;
     HIP_TRY(hipMemcpyAsync(&next, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    // speculate further ahead while (almost) no pixel stops, back off when many do
+    // A pixel that stops inside a round wastes on average half a round of its own samples, so the
+    // share of wasted work is about half the share of pixels that stopped, whatever the group size:
+    // speculate further ahead while at most 5 % stop, back off when more than 20 % do.
     uint32_t stopped = n_active - next;
     if (b + G < rp.max_batches) {
-      if ((uint64_t)stopped * 50 <= n_active) group = std::min(max_group, std::max(1, group * 2));
-      else group = std::max(1, group / 2);
+      if ((uint64_t)stopped * 20 <= n_active) group = std::min(max_group, std::max(rounds == 0 ? first_jump : 1, group * 2));
+      else if ((uint64_t)stopped * 5 > n_active) group = std::max(1, group / 2);
     }
     n_active = next;
     cur ^= 1;
