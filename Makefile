@@ -21,7 +21,7 @@ $(LIBDIR)/librt_hip.so: raytracer_amd/csrc/rt_hip.hip raytracer_amd/csrc/rt_devi
 
 $(LIBDIR)/librt_host.so: $(HOSTSRC) raytracer_amd/csrc/host/scene.hpp raytracer_amd/csrc/host/json.hpp include/rt_host.h include/rt_hip.h $(LIBDIR)/librt_hip.so
 	@mkdir -p $(LIBDIR)
-	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -o $@ $(HOSTSRC) -L$(LIBDIR) -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
+	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -ffp-contract=off -Wall -o $@ $(HOSTSRC) -L$(LIBDIR) -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 oracle/_build/librt_oracle.so: oracle/rt_oracle.c include/rt_hip.h
 	@mkdir -p oracle/_build

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--triangles", type=int, default=100_000)
+    ap.add_argument("--batch", type=int, default=20, help="sample_batch_size (other sizes are not the headline workload)")
+    ap.add_argument("--max-batches", type=int, default=100)
+    ap.add_argument("--min-batches", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--early-terminate", action="store_true", help="set RT_FLAG_EARLY_TERMINATE (same pixels, fewer rays)")
@@ -65,7 +68,8 @@ def main():
 
     # ---- inputs (not timed): generated mesh + scene/config JSON, then the reference's host steps
     workdir = os.path.join(tempfile.gettempdir(), f"rt_bench_{os.getuid()}_{rank}")
-    scene_path, config_path = scenes.materialize_c3(workdir, args.triangles, args.width, args.height)
+    scene_path, config_path = scenes.materialize_c3(workdir, args.triangles, args.width, args.height, batch=args.batch,
+                                                    max_batches=args.max_batches, min_batches=args.min_batches)
     t_host0 = time.time()
     ri = RenderIntegrator.new_from_json(scene_path, config_path).prepare()
     t_host = time.time() - t_host0
@@ -189,7 +193,8 @@ def main():
         achieved = (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         value = rays_all / elapsed / 1e6
         traffic = traffic_note = None
-        if os.path.exists(TRAFFIC_JSON) and args.triangles == 100_000 and (W, H) == (1200, 1200) and not opt_flags:
+        headline = (args.triangles, W, H, args.batch, args.max_batches, args.min_batches) == (100_000, 1200, 1200, 20, 100, 2)
+        if os.path.exists(TRAFFIC_JSON) and headline and not opt_flags:
             with open(TRAFFIC_JSON) as fh:
                 tj = json.load(fh)
             if tj.get("hbm_bytes_per_ray"):

@@ -2,6 +2,8 @@
 // operator surface (/root/reference/src/render/integrator.rs:38-249):
 // new_from_json -> render -> save_to_png, with the Rayon row loop
 // (integrator.rs:226-243) replaced by one call into rt_hip.h.
+#include <cstdlib>
+#include <chrono>
 #include <zlib.h>
 
 #include <cstdio>
@@ -70,9 +72,16 @@ class RenderIntegrator {
     cam.defocus_angle = jc.at("camera_defocus_angle").as_number();
     cam.focus_dist = jc.at("camera_focus_dist").as_number();
     scene.camera = make_camera(config, cam);
+    auto t0 = std::chrono::steady_clock::now();
     expand_elements(scene_json, base_dir, scene);
     if (scene.elements.empty()) throw std::runtime_error("scene has no elements");
+    auto t1 = std::chrono::steady_clock::now();
     build_bvh(scene, config.has_split_method ? config.split_method : SplitMethod::Mid);  // integrator.rs:183-189
+    auto t2 = std::chrono::steady_clock::now();
+    if (std::getenv("RT_HOST_VERBOSE"))
+      std::fprintf(stderr, "rt_host: %zu elements expanded in %.3f s, BVH (%zu nodes, depth %d) built in %.3f s on up to %d threads\n",
+                   scene.elements.size(), std::chrono::duration<double>(t1 - t0).count(), scene.nodes.size(), scene.bvh_depth,
+                   std::chrono::duration<double>(t2 - t1).count(), host_threads());
 
     pod.camera = scene.camera;
     pod.n_nodes = (int32_t)scene.nodes.size();

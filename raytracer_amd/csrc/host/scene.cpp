@@ -4,11 +4,14 @@
 // that the POD scene handed to rt_hip.h is the one the Rust host would build.
 #include "scene.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 namespace rt {
 
@@ -126,19 +129,25 @@ RtCamera make_camera(const Config &cfg, const JsonCamera &jc) {
 }
 
 // ------------------------------------------------------- element builders
-void SceneData::add_triangle(Vec3 v0, Vec3 v1, Vec3 v2, int material) {
+// Triangle::new, triangle.rs:55-70: the record and the element (with its padded box) for slot `index`.
+static void make_triangle(Vec3 v0, Vec3 v1, Vec3 v2, int material, int index, RtTriangle &t, Element &e) {
   Vec3 v0v1 = v1 - v0, v0v2 = v2 - v0;
   Vec3 normal = normalized(cross(v0v1, v0v2));
-  RtTriangle t{};
+  t = RtTriangle{};
   t.v0 = abi(v0);
   t.v0v1 = abi(v0v1);
   t.v0v2 = abi(v0v2);
   t.normal = abi(normal);
   t.material = material;
-  Element e;
   e.kind = RT_PRIM_TRIANGLE;
-  e.index = (int)triangles.size();
+  e.index = index;
   e.bbox = Aabb::from_points(vmin(v0, vmin(v1, v2)), vmax(v0, vmax(v1, v2))).pad();
+}
+
+void SceneData::add_triangle(Vec3 v0, Vec3 v1, Vec3 v2, int material) {
+  RtTriangle t;
+  Element e;
+  make_triangle(v0, v1, v2, material, (int)triangles.size(), t, e);
   triangles.push_back(t);
   elements.push_back(e);
 }
@@ -295,76 +304,187 @@ static void add_box(const Json &j, SceneData &out) {
 // (10.0.0, source not in the reference tree): per-object vertex lists with
 // object-local 0-based indices, polygons fan-triangulated, only triangles
 // consumed.  Restated here for `v`, `f` (with v/vt/vn forms), `o`.
+//
+// Large meshes dominate the load time, so the file is read whole and parsed by several threads,
+// each on a run of complete lines; what depends on everything before a line (the running vertex
+// count for relative indices, object boundaries) is resolved once the per-thread counts are known.
+// Vertices are transformed and triangles built in parallel; their order is the file's.
+template <typename F>
+static void parallel_ranges(size_t n, int threads, size_t min_items, F &&fn) {  // fn(begin, end) over [0, n)
+  if (threads <= 1 || n < min_items) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> failures((size_t)threads);
+  for (int c = 0; c < threads; c++)
+    pool.emplace_back([&, c] {
+      try {
+        fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
+      } catch (...) {
+        failures[(size_t)c] = std::current_exception();
+      }
+    });
+  for (auto &t : pool) t.join();
+  for (auto &f : failures)
+    if (f) std::rethrow_exception(f);
+}
+
 static void add_obj(const Json &j, const std::string &base_dir, SceneData &out) {
   std::string path = j.at("filepath").as_string();
   if (!base_dir.empty() && !path.empty() && path[0] != '/') path = base_dir + "/" + path;
   int material = material_from_json(j.at("material"), out);
   Transform tf = transform_from_json(j);
 
-  std::ifstream f(path);
-  if (!f) throw std::runtime_error("cannot open obj file `" + path + "`");
-
-  struct Obj {
-    std::vector<Vec3> vertices;
-    std::vector<int64_t> faces;  // triples of object-local indices
-    size_t first_vertex = 0;     // global index of vertices[0]
-  };
-  std::vector<Obj> objects(1);
-  size_t global_vertices = 0;
-  std::string line;
-  std::vector<int64_t> poly;
-  while (std::getline(f, line)) {
-    const char *p = line.c_str();
-    while (*p == ' ' || *p == '\t') p++;
-    if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
-      char *end;
-      double x = std::strtod(p + 1, &end);
-      double y = std::strtod(end, &end);
-      double z = std::strtod(end, &end);
-      objects.back().vertices.push_back({x, y, z});
-      global_vertices++;
-    } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
-      poly.clear();
-      const char *q = p + 1;
-      while (*q) {
-        while (*q == ' ' || *q == '\t' || *q == '\r') q++;
-        if (!*q) break;
-        char *end;
-        long long idx = std::strtoll(q, &end, 10);
-        if (end == q) throw std::runtime_error("obj: bad face index in `" + path + "`");
-        if (idx < 0) idx = (long long)global_vertices + idx + 1;  // relative index
-        poly.push_back((int64_t)idx - 1 - (int64_t)objects.back().first_vertex);
-        q = end;
-        while (*q && *q != ' ' && *q != '\t' && *q != '\r') q++;  // skip /vt/vn
-      }
-      for (size_t k = 1; k + 1 < poly.size(); k++) {
-        objects.back().faces.push_back(poly[0]);
-        objects.back().faces.push_back(poly[k]);
-        objects.back().faces.push_back(poly[k + 1]);
-      }
-    } else if (p[0] == 'o' && (p[1] == ' ' || p[1] == '\t')) {
-      if (!objects.back().vertices.empty() || !objects.back().faces.empty()) {
-        objects.emplace_back();
-        objects.back().first_vertex = global_vertices;
-      }
-    }
+  std::string text;
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open obj file `" + path + "`");
+    f.seekg(0, std::ios::end);
+    std::streamoff size = f.tellg();
+    f.seekg(0, std::ios::beg);
+    text.resize(size > 0 ? (size_t)size : 0);
+    if (size > 0 && !f.read(&text[0], size)) throw std::runtime_error("cannot read obj file `" + path + "`");
   }
 
-  for (auto &o : objects) {
-    std::vector<Vec3> &v = o.vertices;
-    if (tf.has_scale) apply_all(mat_scale(tf.scale.x, tf.scale.y, tf.scale.z), v);
-    if (tf.has_rotate) {
-      apply_all(mat_rotate_x(tf.rotate.x), v);
-      apply_all(mat_rotate_y(tf.rotate.y), v);
-      apply_all(mat_rotate_z(tf.rotate.z), v);
+  // ---- parse: each chunk starts after a newline and ends after one
+  struct Chunk {
+    std::vector<Vec3> vertices;
+    std::vector<int64_t> tri;        // 3 per triangle: a global 1-based index, or for a relative
+    std::vector<uint8_t> tri_rel;    //   one (bit k set) its value + 1 + vertices seen so far in the chunk
+    struct Marker { size_t vertices_before, tris_before; };
+    std::vector<Marker> objects;     // `o` lines
+  };
+  size_t chunk_bytes = 1 << 20;  // least text worth a thread
+  if (const char *v = std::getenv("RT_HOST_PARSE_CHUNK"))
+    if (std::atoll(v) >= 1) chunk_bytes = (size_t)std::atoll(v);
+  const int threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), text.size() / chunk_bytes + 1));
+  std::vector<size_t> cut((size_t)threads + 1, text.size());
+  cut[0] = 0;
+  for (int c = 1; c < threads; c++) {
+    size_t at = text.find('\n', text.size() * (size_t)c / (size_t)threads);
+    cut[(size_t)c] = at == std::string::npos ? text.size() : at + 1;
+  }
+  std::vector<Chunk> chunks((size_t)threads);
+  parallel_ranges((size_t)threads, threads, 2, [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; c++) {
+      Chunk &ch = chunks[c];
+      std::vector<int64_t> poly;
+      std::vector<uint8_t> poly_rel;
+      const char *p = text.data() + cut[c], *stop = text.data() + cut[c + 1];
+      while (p < stop) {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(stop - p));
+        if (!eol) eol = stop;
+        // strtod/strtoll stop at the newline themselves; the last line of the file is NUL-terminated by std::string
+        while (p < eol && (*p == ' ' || *p == '\t')) p++;
+        if (eol - p >= 2 && p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+          // strtod skips newlines like any blank: a line with fewer than three numbers must not
+          // borrow from the next one (missing coordinates read as 0, as they would from the line alone)
+          double xyz[3] = {0.0, 0.0, 0.0};
+          const char *q = p + 1;
+          for (int k = 0; k < 3; k++) {
+            while (q < eol && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+            if (q >= eol) break;
+            char *end;
+            double value = std::strtod(q, &end);
+            if (end == q || end > eol) break;
+            xyz[k] = value;
+            q = end;
+          }
+          ch.vertices.push_back({xyz[0], xyz[1], xyz[2]});
+        } else if (eol - p >= 2 && p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+          poly.clear();
+          poly_rel.clear();
+          const char *q = p + 1;
+          while (q < eol) {
+            while (q < eol && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+            if (q >= eol) break;
+            char *end;
+            long long idx = std::strtoll(q, &end, 10);
+            if (end == q) throw std::runtime_error("obj: bad face index in `" + path + "`");
+            if (idx < 0) {  // relative to the vertices read so far
+              poly.push_back((int64_t)ch.vertices.size() + idx + 1);
+              poly_rel.push_back(1);
+            } else {
+              poly.push_back((int64_t)idx);
+              poly_rel.push_back(0);
+            }
+            q = end;
+            while (q < eol && *q != ' ' && *q != '\t' && *q != '\r') q++;  // skip /vt/vn
+          }
+          for (size_t k = 1; k + 1 < poly.size(); k++) {  // fan
+            ch.tri.push_back(poly[0]);
+            ch.tri.push_back(poly[k]);
+            ch.tri.push_back(poly[k + 1]);
+            ch.tri_rel.push_back((uint8_t)(poly_rel[0] | (poly_rel[k] << 1) | (poly_rel[k + 1] << 2)));
+          }
+        } else if (eol - p >= 2 && p[0] == 'o' && (p[1] == ' ' || p[1] == '\t')) {
+          ch.objects.push_back({ch.vertices.size(), ch.tri_rel.size()});
+        }
+        p = eol < stop ? eol + 1 : stop;
+      }
     }
-    if (tf.has_translate) apply_all(mat_translate(tf.translate.x, tf.translate.y, tf.translate.z), v);
-    for (size_t k = 0; k + 2 < o.faces.size(); k += 3) {
-      int64_t a = o.faces[k], b = o.faces[k + 1], c = o.faces[k + 2];
-      if (a < 0 || b < 0 || c < 0 || a >= (int64_t)v.size() || b >= (int64_t)v.size() || c >= (int64_t)v.size())
-        throw std::runtime_error("obj: face index out of range in `" + path + "`");
-      out.add_triangle(v[a], v[b], v[c], material);
+  });
+
+  // ---- merge: global vertex / triangle numbering and the objects' ranges
+  std::vector<size_t> vbase((size_t)threads + 1, 0), tbase((size_t)threads + 1, 0);
+  for (int c = 0; c < threads; c++) {
+    vbase[(size_t)c + 1] = vbase[(size_t)c] + chunks[(size_t)c].vertices.size();
+    tbase[(size_t)c + 1] = tbase[(size_t)c] + chunks[(size_t)c].tri_rel.size();
+  }
+  const size_t n_vertices = vbase[(size_t)threads], n_tris = tbase[(size_t)threads];
+  struct Range { size_t first_vertex, first_tri; };
+  std::vector<Range> objects{{0, 0}};
+  for (int c = 0; c < threads; c++)
+    for (const auto &m : chunks[(size_t)c].objects) {
+      size_t gv = vbase[(size_t)c] + m.vertices_before, gt = tbase[(size_t)c] + m.tris_before;
+      if (gv > objects.back().first_vertex || gt > objects.back().first_tri) objects.push_back({gv, gt});  // a non-empty object ends here
     }
+  objects.push_back({n_vertices, n_tris});  // sentinel
+
+  std::vector<Vec3> vertices(n_vertices);
+  std::vector<int64_t> tri(3 * n_tris);
+  parallel_ranges((size_t)threads, threads, 2, [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; c++) {
+      const Chunk &ch = chunks[c];
+      std::copy(ch.vertices.begin(), ch.vertices.end(), vertices.begin() + (long)vbase[c]);
+      for (size_t t = 0; t < ch.tri_rel.size(); t++)
+        for (int k = 0; k < 3; k++) tri[3 * (tbase[c] + t) + (size_t)k] = ch.tri[3 * t + (size_t)k] + (((ch.tri_rel[t] >> k) & 1) ? (int64_t)vbase[c] : 0);
+    }
+  });
+  std::vector<Chunk>().swap(chunks);
+
+  // ---- transform (obj.rs:48-78: scale, rotate x, y, z, translate -- one matrix at a time)
+  std::vector<Mat4> steps;
+  if (tf.has_scale) steps.push_back(mat_scale(tf.scale.x, tf.scale.y, tf.scale.z));
+  if (tf.has_rotate) {
+    steps.push_back(mat_rotate_x(tf.rotate.x));
+    steps.push_back(mat_rotate_y(tf.rotate.y));
+    steps.push_back(mat_rotate_z(tf.rotate.z));
+  }
+  if (tf.has_translate) steps.push_back(mat_translate(tf.translate.x, tf.translate.y, tf.translate.z));
+  const int workers = host_threads();
+  parallel_ranges(n_vertices, workers, 4096, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++)
+      for (const Mat4 &m : steps) vertices[i] = m.apply(vertices[i]);
+  });
+
+  // ---- triangles, in file order; indices are local to their object (obj.rs:83-99)
+  const size_t first_triangle = out.triangles.size(), first_element = out.elements.size();
+  out.triangles.resize(first_triangle + n_tris);
+  out.elements.resize(first_element + n_tris);
+  for (size_t o = 0; o + 1 < objects.size(); o++) {
+    const size_t v0 = objects[o].first_vertex, nv = objects[o + 1].first_vertex - v0;
+    const size_t t0 = objects[o].first_tri, nt = objects[o + 1].first_tri - t0;
+    parallel_ranges(nt, workers, 4096, [&](size_t b, size_t e) {
+      for (size_t t = t0 + b; t < t0 + e; t++) {
+        int64_t ia = tri[3 * t] - 1 - (int64_t)v0, ib = tri[3 * t + 1] - 1 - (int64_t)v0, ic = tri[3 * t + 2] - 1 - (int64_t)v0;
+        if (ia < 0 || ib < 0 || ic < 0 || ia >= (int64_t)nv || ib >= (int64_t)nv || ic >= (int64_t)nv)
+          throw std::runtime_error("obj: face index out of range in `" + path + "`");
+        make_triangle(vertices[v0 + (size_t)ia], vertices[v0 + (size_t)ib], vertices[v0 + (size_t)ic], material, (int)(first_triangle + t),
+                      out.triangles[first_triangle + t], out.elements[first_element + t]);
+      }
+    });
   }
 }
 

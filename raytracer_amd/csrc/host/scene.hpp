@@ -104,5 +104,6 @@ void expand_elements(const Json &scene, const std::string &base_dir, SceneData &
 
 // bvh_node_sah.rs:147-159, 256-461
 void build_bvh(SceneData &scene, SplitMethod method);
+int host_threads();
 
 }  // namespace rt

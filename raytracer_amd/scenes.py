@@ -215,12 +215,12 @@ def scene_c3(obj_path, defocus_angle=0.0):
     return {"camera": camera(defocus_angle=defocus_angle), "elements": els}
 
 
-def config_c3(width=1200, height=1200):
+def config_c3(width=1200, height=1200, batch=20, max_batches=100, min_batches=2):
     """README render: batches of 20, at most 100 batches (2000 spp), at least 2."""
-    return config(width, height, 20, 100, 2)
+    return config(width, height, batch, max_batches, min_batches)
 
 
-def materialize_c3(directory, n_triangles=100_000, width=1200, height=1200, seed=7):
+def materialize_c3(directory, n_triangles=100_000, width=1200, height=1200, seed=7, batch=20, max_batches=100, min_batches=2):
     """Write mesh.obj + scene.json + config.json for the C3 workload; returns the two JSON paths."""
     os.makedirs(directory, exist_ok=True)
     obj_path = os.path.join(directory, f"knot_{n_triangles}.obj")
@@ -234,7 +234,7 @@ def materialize_c3(directory, n_triangles=100_000, width=1200, height=1200, seed
     with open(scene_path, "w") as f:
         json.dump(scene_c3(obj_path), f)
     with open(config_path, "w") as f:
-        json.dump(config_c3(width, height), f)
+        json.dump(config_c3(width, height, batch, max_batches, min_batches), f)
     return scene_path, config_path
 
 

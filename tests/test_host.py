@@ -144,6 +144,58 @@ def test_obj_loader_fan_and_slashes(tmp_path):
     assert sc.triangles[2].v0.tuple() == (0.0, 0.0, 0.0)
 
 
+def test_obj_loader_parallel_parse_is_order_exact(tmp_path, monkeypatch):
+    """The loader splits big files over threads; objects, relative indices, polygons and the
+    order of the triangles must come out as from a single pass."""
+    rng = np.random.RandomState(4)
+    lines, n_v = ["# generated"], 0
+    for obj in range(5):
+        lines.append(f"o part{obj}")
+        first = n_v
+        for _ in range(300):
+            x, y, z = rng.uniform(-3, 3, size=3)
+            lines.append(f"v {x:.6f} {y:.6f} {z:.6f}")
+            n_v += 1
+            if n_v - first >= 4 and rng.uniform() < 0.7:
+                k = rng.randint(3, 6)
+                if rng.uniform() < 0.5:  # absolute (file-wide) indices into this object, with /vt/vn decorations
+                    idx = rng.randint(first + 1, n_v + 1, size=k)
+                    lines.append("f " + " ".join(f"{i}/1/1" for i in idx))
+                else:                    # relative ones
+                    idx = -rng.randint(1, n_v - first + 1, size=k)
+                    lines.append("f " + " ".join(str(i) for i in idx))
+        lines.append("vn 0 0 1")
+    p = tmp_path / "parts.obj"
+    p.write_text("\n".join(lines) + "\n")
+    scene = {"camera": scenes.camera(), "elements": [scenes.obj_element(str(p), scenes.lambertian(.5, .5, .5), scale=(2, 3, 4),
+                                                                          rotate=(0.1, -0.7, 0.3), transpose=(5, 6, 7))]}
+
+    def load():
+        ri = RenderIntegrator.new(scene, scenes.config(8, 8, 1, 1, 1)).prepare()
+        sc = ri.scene.contents
+        tri = np.array([sc.triangles[i].v0.tuple() + sc.triangles[i].v0v1.tuple() + sc.triangles[i].v0v2.tuple() + sc.triangles[i].normal.tuple()
+                        for i in range(sc.n_triangles)])
+        return tri, _scene_arrays(ri)[1]
+
+    monkeypatch.setenv("RT_HOST_THREADS", "1")
+    tri1, nodes1 = load()
+    assert len(tri1) > 1500
+    monkeypatch.setenv("RT_HOST_THREADS", "7")
+    monkeypatch.setenv("RT_HOST_PARSE_CHUNK", "997")
+    tri7, nodes7 = load()
+    assert np.array_equal(tri1, tri7, equal_nan=True)  # repeated indices give degenerate triangles with NaN normals
+    assert nodes1 == nodes7
+
+
+def test_obj_loader_rejects_indices_outside_the_object(tmp_path):
+    p = tmp_path / "bad.obj"
+    p.write_text("o a\nv 0 0 0\nv 1 0 0\nv 0 1 0\no b\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf 1 2 3\n")  # face of b names a's vertices
+    scene = {"camera": scenes.camera(), "elements": [scenes.obj_element(str(p), scenes.lambertian(.5, .5, .5))]}
+    with pytest.raises(abi.RtError) as e:
+        RenderIntegrator.new(scene, scenes.config(8, 8, 1, 1, 1)).prepare()
+    assert "out of range" in str(e.value)
+
+
 def test_teapot_like_counts(tmp_scene_dir):
     ri = knot_scene(tmp_scene_dir, 6320, 16, 16, 1, 1, 1)
     sc = ri.scene.contents
