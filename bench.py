@@ -162,7 +162,7 @@ def main():
         probe = ref_cfg.copy()
         probe.row_first, probe.row_stride = H // 2, H  # one row through the middle of the image
         t_p = time.perf_counter()
-        oracle.render(ri.scene, probe, threads)
+        _, st_probe = oracle.render(ri.scene, probe, 1)
         # one row on one thread; `threads` rows run concurrently in the sample
         per_row = max(time.perf_counter() - t_p, 1e-3)
         rows_wanted = max(threads, int(args.cpu_seconds / per_row * threads))
@@ -178,6 +178,7 @@ def main():
             "unit": "Mrays/s",
             "cores": threads,
             "kind": "port",
+            "single_core_value": st_probe.rays / max(st_probe.wall_ms, 1e-6) / 1e3,
             "sample": f"rows {sample.row_first}::{stride} of the same {W}x{H} workload ({cpu_rows} rows, "
                       f"{int(st_cpu.rays)} rays, {st_cpu.wall_ms / 1e3:.1f} s, reference RNG mode)",
             "rays": int(st_cpu.rays),

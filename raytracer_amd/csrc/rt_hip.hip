@@ -28,8 +28,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <exception>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_device.h"
@@ -1031,10 +1034,40 @@ int rt_hip_scene_free(RtSceneHandle *h) {
   return RT_OK;
 }
 
+// Host threads for the per-element loops of an upload: RT_HOST_THREADS, else OMP_NUM_THREADS,
+// else the hardware concurrency; never more than 64.
+static int upload_threads() {
+  for (const char *name : {"RT_HOST_THREADS", "OMP_NUM_THREADS"})
+    if (const char *v = getenv(name)) {
+      int n = atoi(v);
+      if (n >= 1) return std::min(n, 64);
+    }
+  unsigned hw = std::thread::hardware_concurrency();
+  return hw == 0 ? 1 : (int)std::min(hw, 64u);
+}
+template <typename F>
+static void parallel_for(size_t n, F &&fn) {  // fn(begin, end) over [0, n), exceptions not expected
+  int threads = upload_threads();
+  if (threads <= 1 || n < 65536) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int c = 0; c < threads; c++) pool.emplace_back([&, c] { fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads); });
+  for (auto &t : pool) t.join();
+}
+
 int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   g_error.clear();
   if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
   *out = nullptr;
+  const bool verbose = getenv("RT_HIP_VERBOSE") != nullptr;
+  auto lap_t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    auto now = std::chrono::steady_clock::now();
+    if (verbose) fprintf(stderr, "rt_hip upload: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t0).count());
+    lap_t0 = now;
+  };
   // ---- validate every index before anything reaches a kernel
   if (s->n_nodes <= 0 || s->n_elements <= 0 || !s->nodes || !s->elements) return fail(RT_ERR_BAD_ARG, "scene has no nodes or no elements");
   if (s->n_triangles < 0 || s->n_quads < 0 || s->n_spheres < 0 || s->n_materials <= 0 || s->n_attractors < 0 || !s->materials)
@@ -1090,14 +1123,17 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     max_depth = std::max(max_depth, d);
   }
   if (max_depth > kMaxStackDepth) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than 64 levels");
+  lap("validation + depth");
 
-  // Does every child box contain the primitives below it?  (The reference's
-  // quad box, quad.rs:86, does not for quads that are not axis-aligned.)  If
-  // not, k_extend must reproduce the reference's irregular visit rule.
-  bool boxes_bound_contents = true;
+  // Does every child box contain the primitives below it?  (The reference's quad box, quad.rs:86,
+  // does not for quads that are not axis-aligned.)  If not, k_extend must reproduce the
+  // reference's irregular visit rule.  Checked locally, node by node: the box of a leaf child must
+  // contain its primitive and the box of an internal child must contain both boxes stored in that
+  // child -- by induction every box then contains everything below it.  (A tree whose boxes
+  // bound their contents without being nested fails this test and is merely walked the slow way.)
+  std::atomic<bool> nested{true};
   {
     struct B { double mn[3], mx[3]; };
-    std::vector<B> sub((size_t)s->n_nodes);
     auto grow = [](B &b, double x, double y, double z) {
       const double p[3] = {x, y, z};
       for (int a = 0; a < 3; a++) {
@@ -1105,14 +1141,9 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
         if (!(p[a] <= b.mx[a])) b.mx[a] = p[a] != p[a] ? INFINITY : p[a];
       }
     };
-    auto inside = [](const B &b, const double *mn, const double *mx) {
-      for (int a = 0; a < 3; a++)
-        if (!(mn[a] <= b.mn[a] && b.mx[a] <= mx[a])) return false;
-      return true;
-    };
-    for (int i = s->n_nodes - 1; i >= 0; i--) {
-      const RtNode &n = s->nodes[i];
-      B &b = sub[(size_t)i];
+    auto content_of = [&](int32_t child) {  // what the box of `child` has to contain
+      const RtNode &n = s->nodes[child];
+      B b;
       for (int a = 0; a < 3; a++) b.mn[a] = INFINITY, b.mx[a] = -INFINITY;
       if (n.is_leaf) {
         RtElementRef e = s->elements[n.element_index];
@@ -1132,27 +1163,37 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
           grow(b, sp.center.x - rad, sp.center.y - rad, sp.center.z - rad);
           grow(b, sp.center.x + rad, sp.center.y + rad, sp.center.z + rad);
         }
-      } else {
-        const B &l = sub[(size_t)n.child_l_index], &r = sub[(size_t)n.child_r_index];
         // triangle corners are re-derived from v0 + edge, which can round one ulp past the stored box
-        auto slack = [](const B &x) {
-          B y = x;
-          for (int a = 0; a < 3; a++) {
-            double m = std::fmax(std::fabs(y.mn[a]), std::fabs(y.mx[a])) * 4.5e-16;
-            y.mn[a] += m;
-            y.mx[a] -= m;
-          }
-          return y;
-        };
-        if (!inside(slack(l), n.child_l_min, n.child_l_max) || !inside(slack(r), n.child_r_min, n.child_r_max)) boxes_bound_contents = false;
         for (int a = 0; a < 3; a++) {
-          b.mn[a] = std::fmin(l.mn[a], r.mn[a]);
-          b.mx[a] = std::fmax(l.mx[a], r.mx[a]);
+          double m = std::fmax(std::fabs(b.mn[a]), std::fabs(b.mx[a])) * 4.5e-16;
+          b.mn[a] += m;
+          b.mx[a] -= m;
+        }
+      } else {
+        for (int a = 0; a < 3; a++) {
+          b.mn[a] = std::fmin(n.child_l_min[a], n.child_r_min[a]);
+          b.mx[a] = std::fmax(n.child_l_max[a], n.child_r_max[a]);
         }
       }
-    }
+      return b;
+    };
+    auto inside = [](const B &b, const double *mn, const double *mx) {
+      for (int a = 0; a < 3; a++)
+        if (!(mn[a] <= b.mn[a] && b.mx[a] <= mx[a])) return false;
+      return true;
+    };
+    parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
+      bool ok = true;
+      for (size_t i = begin; i < end && ok; i++) {
+        const RtNode &n = s->nodes[i];
+        if (n.is_leaf || depth[i] < 0) continue;
+        ok = inside(content_of(n.child_l_index), n.child_l_min, n.child_l_max) && inside(content_of(n.child_r_index), n.child_r_min, n.child_r_max);
+      }
+      if (!ok) nested.store(false, std::memory_order_relaxed);
+    });
   }
-
+  bool boxes_bound_contents = nested.load();
+  lap("box containment");
   // The reference's leaf order (depth-first, left child first) decides exact ties between
   // primitives; the reordering traversal needs it per element.  An element named by more than
   // one reachable leaf has no single position: such a tree is walked in the reference's order.
@@ -1180,6 +1221,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     }
   }
 
+  lap("leaf order");
   // ---- flatten
   auto ref_of_element = [&](int e) -> uint32_t {
     RtElementRef er = s->elements[e];
@@ -1190,7 +1232,8 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     return n.is_leaf ? ref_of_element(n.element_index) : (uint32_t)internal_index[(size_t)i];
   };
   std::vector<DevNode> nodes((size_t)n_internal);
-  for (int i = 0; i < s->n_nodes; i++) {
+  parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
+  for (size_t i = begin; i < end; i++) {
     const RtNode &n = s->nodes[i];
     if (n.is_leaf) continue;
     DevNode &d = nodes[(size_t)internal_index[(size_t)i]];
@@ -1204,11 +1247,13 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     d.right = ref_of_node(n.child_r_index);
     d.pad[0] = d.pad[1] = 0;
   }
+  });
   std::vector<DevTriangle> tris((size_t)s->n_triangles);
   std::vector<DevTriShade> tri_shade((size_t)s->n_triangles);
   std::vector<DevQuad> quads((size_t)s->n_quads);
   std::vector<DevSphere> spheres((size_t)s->n_spheres);
-  for (int e = 0; e < s->n_elements; e++) {
+  parallel_for((size_t)s->n_elements, [&](size_t begin, size_t end) {
+  for (size_t e = begin; e < end; e++) {
     RtElementRef er = s->elements[e];
     if (er.kind == RT_PRIM_TRIANGLE) {
       const RtTriangle &t = s->triangles[er.index];
@@ -1250,6 +1295,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.pad = 0;
     }
   }
+  });
   std::vector<DevMaterial> mats((size_t)s->n_materials);
   for (int i = 0; i < s->n_materials; i++) {
     mats[(size_t)i].albedo[0] = s->materials[i].albedo[0];
@@ -1262,6 +1308,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   std::vector<uint32_t> attractors((size_t)s->n_attractors);
   for (int i = 0; i < s->n_attractors; i++) attractors[(size_t)i] = ref_of_element(s->attractors[i]);
 
+  lap("flatten");
   // ---- upload
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1295,6 +1342,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   h->dev.stack_depth = std::max(max_depth, 1);
   h->dev.quirk = boxes_bound_contents ? 0 : 1;
   h->dev.camera = s->camera;
+  lap("device copies");
   *out = h;
   return RT_OK;
 }
