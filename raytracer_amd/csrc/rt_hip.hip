@@ -1198,6 +1198,14 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   // primitives; the reordering traversal needs it per element.  An element named by more than
   // one reachable leaf has no single position: such a tree is walked in the reference's order.
   std::vector<uint32_t> leaf_rank_of_element((size_t)s->n_elements, 0xffffffffu);
+  // Triangle records are stored in that leaf order too: triangles that are close in the tree,
+  // hence in space, share cache lines whatever their order in the caller's array.
+  std::vector<uint32_t> tri_slot((size_t)s->n_triangles, 0xffffffffu);
+  uint32_t next_tri_slot = 0;
+  auto place_triangle = [&](int32_t element) {
+    RtElementRef er = s->elements[element];
+    if (er.kind == RT_PRIM_TRIANGLE && tri_slot[(size_t)er.index] == 0xffffffffu) tri_slot[(size_t)er.index] = next_tri_slot++;
+  };
   {
     std::vector<int32_t> todo{0};
     uint32_t next_rank = 0;
@@ -1214,6 +1222,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
         uint32_t &r = leaf_rank_of_element[(size_t)n.element_index];
         if (r != 0xffffffffu) boxes_bound_contents = false;
         r = next_rank++;
+        place_triangle(n.element_index);
       } else {
         todo.push_back(n.child_r_index);
         todo.push_back(n.child_l_index);
@@ -1221,11 +1230,15 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     }
   }
 
+  for (int e = 0; e < s->n_elements; e++) place_triangle(e);  // elements no reachable leaf names
+  for (uint32_t &slot : tri_slot)
+    if (slot == 0xffffffffu) slot = next_tri_slot++;            // triangles no element names
   lap("leaf order");
   // ---- flatten
   auto ref_of_element = [&](int e) -> uint32_t {
     RtElementRef er = s->elements[e];
-    return kRefLeaf | ((uint32_t)er.kind << kRefKindShift) | (uint32_t)er.index;
+    uint32_t index = er.kind == RT_PRIM_TRIANGLE ? tri_slot[(size_t)er.index] : (uint32_t)er.index;
+    return kRefLeaf | ((uint32_t)er.kind << kRefKindShift) | index;
   };
   auto ref_of_node = [&](int i) -> uint32_t {
     const RtNode &n = s->nodes[i];
@@ -1257,13 +1270,13 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     RtElementRef er = s->elements[e];
     if (er.kind == RT_PRIM_TRIANGLE) {
       const RtTriangle &t = s->triangles[er.index];
-      DevTriangle &d = tris[(size_t)er.index];
+      DevTriangle &d = tris[(size_t)tri_slot[(size_t)er.index]];
       d.v0[0] = t.v0.x; d.v0[1] = t.v0.y; d.v0[2] = t.v0.z;
       d.e1[0] = t.v0v1.x; d.e1[1] = t.v0v1.y; d.e1[2] = t.v0v1.z;
       d.e2[0] = t.v0v2.x; d.e2[1] = t.v0v2.y; d.e2[2] = t.v0v2.z;
       d.element = (uint32_t)e;
       d.rank = leaf_rank_of_element[(size_t)e];
-      DevTriShade &sh = tri_shade[(size_t)er.index];
+      DevTriShade &sh = tri_shade[(size_t)tri_slot[(size_t)er.index]];
       const RtMaterial &m = s->materials[t.material];
       sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
       sh.albedo[0] = m.albedo[0]; sh.albedo[1] = m.albedo[1]; sh.albedo[2] = m.albedo[2];
