@@ -40,6 +40,15 @@ struct __attribute__((aligned(64))) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "node must be one 64-byte record");
 
+// 32-byte internal node: the same two child boxes on a 16-bit grid spanning the scene's
+// bounds (min corners rounded down, max corners up), + child refs.  Half the bytes of DevNode:
+// the node set of a 100 000-triangle scene (3.2 MB) then fits one XCD's L2.
+struct __attribute__((aligned(32))) DevNodeQ {
+  uint16_t lmin[3], lmax[3], rmin[3], rmax[3];
+  uint32_t left, right;
+};
+static_assert(sizeof(DevNodeQ) == 32, "quantised node must be one 32-byte record");
+
 // 80-byte triangle record read by the leaf test (triangle.rs:76-117).
 struct __attribute__((aligned(16))) DevTriangle {
   double v0[3], e1[3], e2[3];
@@ -79,6 +88,8 @@ struct DevMaterial {
 
 struct DevScene {
   const DevNode *nodes;
+  const DevNodeQ *nodes_q;  // non-null when the 16-bit grid is fine enough for this scene
+  double grid_min[3], grid_step[3];  // grid value q on axis a stands for grid_min[a] + q * grid_step[a]
   const DevTriangle *triangles;
   const DevTriShade *tri_shade;
   const DevQuad *quads;
@@ -383,6 +394,49 @@ RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, flo
   return tn <= fminf(tf, tmax) * 1.000001f;
 }
 
+// Ray constants for boxes on the 16-bit grid: the slab distance of grid value q on axis a is
+// (grid_min + q*step - o) / d = q * A + B with A = step/d and B = (grid_min - o)/d, one fma.
+// A and B are rounded from f64 and the fma rounds once more; per axis, e bounds the sum of those
+// errors, and it is folded into the constants: the plane the ray meets first uses B - e, the
+// other one B + e (which of the two grid values that is depends on the sign of A only), so the
+// computed interval contains the exact one.  The widening must be per axis: for a ray almost
+// parallel to an axis |A| and e are huge there, and a single bound would pass every box.
+struct RayQ {
+  float ax, ay, az;
+  float blx, bly, blz;  // added to q_min * A
+  float bhx, bhy, bhz;  // added to q_max * A
+};
+RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out, float &bl_out, float &bh_out) {
+  double inv = 1.0 / d;
+  double a = step * inv, b = (gmin - o) * inv;
+  // |q*A| <= 65535 |A|; each term is off by at most 2^-24 relative, the result by another 2^-24
+  double e = (65535.0 * fabs(a) + fabs(b)) * 2.4e-7 + 1e-30;
+  if (!(e <= kF64Max)) e = 0.0;  // d == 0: the products are inf/NaN and the axis drops out of min/max
+  a_out = (float)a;
+  double b_near = b - e, b_far = b + e;
+  // a >= 0: q_min gives the near plane; a < 0: q_max does
+  bl_out = a >= 0.0 ? __double2float_rd(b_near) : __double2float_ru(b_far);
+  bh_out = a >= 0.0 ? __double2float_ru(b_far) : __double2float_rd(b_near);
+}
+RT_DEV RayQ make_rayq(const DevScene &sc, d3 o, d3 d) {
+  RayQ r;
+  rayq_axis(sc.grid_step[0], sc.grid_min[0], o.x, d.x, r.ax, r.blx, r.bhx);
+  rayq_axis(sc.grid_step[1], sc.grid_min[1], o.y, d.y, r.ay, r.bly, r.bhy);
+  rayq_axis(sc.grid_step[2], sc.grid_min[2], o.z, d.z, r.az, r.blz, r.bhz);
+  return r;
+}
+// Conservative slab test on the grid: passes whenever the reference's f64 test on the original
+// box does, and never rejects a box that begins at or before `tmax`.
+RT_DEV bool slab_hit_q(float qminx, float qminy, float qminz, float qmaxx, float qmaxy, float qmaxz, const RayQ &r, float tmax, float &tn_out) {
+  float tlx = fmaf(qminx, r.ax, r.blx), thx = fmaf(qmaxx, r.ax, r.bhx);
+  float tly = fmaf(qminy, r.ay, r.bly), thy = fmaf(qmaxy, r.ay, r.bhy);
+  float tlz = fmaf(qminz, r.az, r.blz), thz = fmaf(qmaxz, r.az, r.bhz);
+  float tn = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), 0.0f));
+  float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+  tn_out = tn;
+  return tn <= fminf(tf, tmax);
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // Per-lane traversal state.  `stack` / `leafq` point at this lane's slot of
@@ -492,6 +546,31 @@ RT_DEV void trav_node(const DevScene &sc, const RayF &f, Traversal &tv, uint32_t
     tv.cur = right;
   } else {
     trav_pop<QUIRK>(tv, stack, stride);
+  }
+}
+
+// The node step on the 32-byte grid records (order-free walk only).
+RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, uint32_t *stack, int stride) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(&sc.nodes_q[tv.cur & kRefIndexMask]);
+  uint4 w0 = p[0], w1 = p[1];
+  // halves of the words, in the order of DevNodeQ
+  float lminx = (float)(w0.x & 0xffffu), lminy = (float)(w0.x >> 16), lminz = (float)(w0.y & 0xffffu);
+  float lmaxx = (float)(w0.y >> 16), lmaxy = (float)(w0.z & 0xffffu), lmaxz = (float)(w0.z >> 16);
+  float rminx = (float)(w0.w & 0xffffu), rminy = (float)(w0.w >> 16), rminz = (float)(w1.x & 0xffffu);
+  float rmaxx = (float)(w1.x >> 16), rmaxy = (float)(w1.y & 0xffffu), rmaxz = (float)(w1.y >> 16);
+  uint32_t left = w1.z, right = w1.w;
+  float tl, tr;
+  bool hl = slab_hit_q(lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, r, tv.tcull, tl);
+  bool hr = slab_hit_q(rminx, rminy, rminz, rmaxx, rmaxy, rmaxz, r, tv.tcull, tr);
+  if (hl && hr) {
+    bool swap = tr < tl;
+    stack[tv.sp * stride] = swap ? left : right;
+    tv.sp++;
+    tv.cur = swap ? right : left;
+  } else if (hl || hr) {
+    tv.cur = hl ? left : right;
+  } else {
+    trav_pop<false>(tv, stack, stride);
   }
 }
 

@@ -196,7 +196,7 @@ struct ExtendTuning {
   int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
 };
 
-template <bool QUIRK, bool COUNT>
+template <bool QUIRK, bool COUNT, bool GRID>
 __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
                                                 ExtendTuning tune, unsigned long long *visit_counters) {
   const uint32_t lane = threadIdx.x;
@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   uint32_t j = kNoRay;
   d3 ro = D3(0, 0, 0), rd = D3(0, 0, 1);
   RayF f = {};
+  RayQ fq = {};
   Traversal tv;
   trav_begin(sc, tv);
   tv.cur = kDone;
@@ -243,7 +244,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           j = cand;
           ro = D3(q.ox[j], q.oy[j], q.oz[j]);
           rd = D3(q.dx[j], q.dy[j], q.dz[j]);
-          f = make_rayf(ro, rd);
+          if (GRID) fq = make_rayq(sc, ro, rd);
+          else f = make_rayf(ro, rd);
           trav_begin(sc, tv);
         }
         w_next = min(w_end, w_next + (uint32_t)n_idle);
@@ -262,7 +264,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
       if (COUNT) wn++;
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
-        trav_node<QUIRK>(sc, f, tv, stack, stride);
+        if (GRID) trav_node_q(sc, fq, tv, stack, stride);
+        else trav_node<QUIRK>(sc, f, tv, stack, stride);
       }
       if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
@@ -321,11 +324,14 @@ static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t 
   dim3 g(grid), b(64);
   size_t lds = extend_lds_bytes(sc);
   if (quirk) {
-    if (counted) hipLaunchKernelGGL((k_extend<true, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
-    else hipLaunchKernelGGL((k_extend<true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    if (counted) hipLaunchKernelGGL((k_extend<true, true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    else hipLaunchKernelGGL((k_extend<true, false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+  } else if (sc.nodes_q) {
+    if (counted) hipLaunchKernelGGL((k_extend<false, true, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    else hipLaunchKernelGGL((k_extend<false, false, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
   } else {
-    if (counted) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
-    else hipLaunchKernelGGL((k_extend<false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    if (counted) hipLaunchKernelGGL((k_extend<false, true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    else hipLaunchKernelGGL((k_extend<false, false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
   }
 }
 
@@ -1261,6 +1267,75 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     d.pad[0] = d.pad[1] = 0;
   }
   });
+  // ---- the same boxes on a 16-bit grid over the bounds of all child boxes.  Used only by the
+  // order-free walk, and only if the grid is fine compared with the boxes: a cell much larger
+  // than a typical box would make every box test pass.
+  std::vector<DevNodeQ> nodes_q;
+  double grid_min[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
+  if (boxes_bound_contents && !getenv("RT_HIP_NO_GRID")) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool finite = true;
+    for (int i = 0; i < s->n_nodes; i++) {
+      const RtNode &n = s->nodes[i];
+      if (n.is_leaf || depth[(size_t)i] < 0) continue;
+      for (int a = 0; a < 3; a++) {
+        const double v[4] = {n.child_l_min[a], n.child_l_max[a], n.child_r_min[a], n.child_r_max[a]};
+        for (double x : v) {
+          if (!(std::fabs(x) <= 1e30)) finite = false;
+          lo[a] = std::fmin(lo[a], x);
+          hi[a] = std::fmax(hi[a], x);
+        }
+      }
+    }
+    if (finite && n_internal > 0) {
+      for (int a = 0; a < 3; a++) {
+        grid_min[a] = lo[a];
+        grid_step[a] = (hi[a] - lo[a]) / 65535.0;
+        if (!(grid_step[a] > 0.0)) grid_step[a] = 1.0;
+        grid_step[a] *= 1.0 + 1e-12;  // the top grid value must reach hi[a] in spite of rounding
+      }
+      nodes_q.resize((size_t)n_internal);
+      // grid value at or below x / at or above x, checked against the value the kernel's constants stand for
+      auto q_down = [&](double x, int a) {
+        double q = std::floor((x - grid_min[a]) / grid_step[a]);
+        while (q > 0.0 && grid_min[a] + q * grid_step[a] > x - std::fabs(x) * 1e-15) q -= 1.0;
+        return (uint16_t)std::fmin(std::fmax(q, 0.0), 65535.0);
+      };
+      auto q_up = [&](double x, int a) {
+        double q = std::ceil((x - grid_min[a]) / grid_step[a]);
+        while (q < 65535.0 && grid_min[a] + q * grid_step[a] < x + std::fabs(x) * 1e-15) q += 1.0;
+        return (uint16_t)std::fmin(std::fmax(q, 0.0), 65535.0);
+      };
+      std::vector<double> growth((size_t)upload_threads() + 1, 0.0), size((size_t)upload_threads() + 1, 0.0);
+      std::atomic<int> slot_counter{0};
+      parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
+        double my_growth = 0.0, my_size = 0.0;
+        for (size_t i = begin; i < end; i++) {
+          const RtNode &n = s->nodes[i];
+          if (n.is_leaf) continue;
+          DevNodeQ &d = nodes_q[(size_t)internal_index[i]];
+          for (int a = 0; a < 3; a++) {
+            d.lmin[a] = q_down(n.child_l_min[a], a);
+            d.lmax[a] = q_up(n.child_l_max[a], a);
+            d.rmin[a] = q_down(n.child_r_min[a], a);
+            d.rmax[a] = q_up(n.child_r_max[a], a);
+            my_growth += ((double)(d.lmax[a] - d.lmin[a]) + (double)(d.rmax[a] - d.rmin[a])) * grid_step[a];
+            my_size += (n.child_l_max[a] - n.child_l_min[a]) + (n.child_r_max[a] - n.child_r_min[a]);
+          }
+          d.left = ref_of_node(n.child_l_index);
+          d.right = ref_of_node(n.child_r_index);
+        }
+        int slot = slot_counter.fetch_add(1);
+        growth[(size_t)slot] = my_growth;
+        size[(size_t)slot] = my_size;
+      });
+      double total_growth = 0.0, total_size = 0.0;
+      for (double g : growth) total_growth += g;
+      for (double z : size) total_size += z;
+      // summed edge lengths of the grid boxes vs the original ones: accept up to 10 % more
+      if (!(total_growth <= 1.10 * total_size)) nodes_q.clear();
+    }
+  }
   std::vector<DevTriangle> tris((size_t)s->n_triangles);
   std::vector<DevTriShade> tri_shade((size_t)s->n_triangles);
   std::vector<DevQuad> quads((size_t)s->n_quads);
@@ -1337,6 +1412,9 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     if (rc == RT_OK) rc = r;
   };
   step(dev_upload(h, &h->dev.nodes, nodes));
+  h->dev.nodes_q = nullptr;
+  if (!nodes_q.empty()) step(dev_upload(h, &h->dev.nodes_q, nodes_q));
+  for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
   step(dev_upload(h, &h->dev.triangles, tris));
   step(dev_upload(h, &h->dev.tri_shade, tri_shade));
   step(dev_upload(h, &h->dev.quads, quads));
