@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         uint32_t cand = w_next + (uint32_t)__popcll(idle & lt_mask);
         if (j == kNoRay && cand < w_end) {
           j = cand;
-          ro = D3(q.ox[j], q.oy[j], q.oz[j]);
-          rd = D3(q.dx[j], q.dy[j], q.dz[j]);
+          // queue entries are read once: streaming loads leave the L2 to the nodes and triangles
+          ro = D3(__builtin_nontemporal_load(&q.ox[j]), __builtin_nontemporal_load(&q.oy[j]), __builtin_nontemporal_load(&q.oz[j]));
+          rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
           if (GRID) fq = make_rayq(sc, ro, rd);
           else f = make_rayf(ro, rd);
           trav_begin(sc, tv);
@@ -287,8 +288,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     }
     // ---------------------------------------------------------------- retire
     if (tv.cur == kDone && tv.qn == 0 && j != kNoRay) {
-      hits.t[j] = tv.best.t;
-      hits.ref[j] = tv.best.ref;
+      __builtin_nontemporal_store(tv.best.t, &hits.t[j]);
+      __builtin_nontemporal_store(tv.best.ref, &hits.ref[j]);
       j = kNoRay;
     }
   }
