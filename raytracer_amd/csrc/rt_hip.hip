@@ -1334,6 +1334,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       for (double g : growth) total_growth += g;
       for (double z : size) total_size += z;
       // summed edge lengths of the grid boxes vs the original ones: accept up to 10 % more
+      if (verbose) fprintf(stderr, "rt_hip upload: boxes on the 16-bit grid are %.1f %% larger (summed edges)\n", 100.0 * (total_growth / total_size - 1.0));
       if (!(total_growth <= 1.10 * total_size)) nodes_q.clear();
     }
   }
