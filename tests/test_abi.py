@@ -113,3 +113,16 @@ def test_the_package_has_no_cpu_rendering_path():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("CPU oracle", "").replace("the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_rust_bindings_are_generated_from_the_same_structures():
+    """bindings/rust/rt-hip-sys/src/lib.rs is written from the ctypes mirror whose layout the test
+    above checks against gcc; the committed file must be what the generator writes today."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(os.path.join(root, "bindings", "rust", "rt-hip-sys", "src", "lib.rs")).read()
+    for sym in abi.HIP_SYMBOLS:
+        assert f"pub fn {sym}(" in text, sym
