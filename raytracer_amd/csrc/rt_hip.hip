@@ -339,10 +339,12 @@ static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t 
 // ===================================================================== shade
 // HittablePDF::value over the attractor list (pdf.rs:98-107) with
 // Quad::pdf_value (quad.rs:155-167) / Sphere::pdf_value (sphere.rs:154-169).
-__device__ double attractor_pdf_value(const DevScene &sc, d3 origin, d3 direction) {
+// `renormalized` = normalized(direction): what Ray::new makes of it again inside every pdf_value
+// (quad.rs:157, sphere.rs:157); the caller has it already for the cosine density.
+__device__ double attractor_pdf_value(const DevScene &sc, d3 origin, d3 direction, d3 renormalized) {
   double weight = 1.0 / (double)sc.n_attractors;
   double sum = 0.0;
-  Ray probe = {origin, normalized(direction), D3(0, 0, 0)};  // Ray::new re-normalises; the tests below never read inv
+  Ray probe = {origin, renormalized, D3(0, 0, 0)};  // the tests below never read inv
   for (int a = 0; a < sc.n_attractors; a++) {
     uint32_t ref = sc.attractors[a];
     uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
@@ -394,8 +396,8 @@ __device__ d3 attractor_generate(const DevScene &sc, d3 origin, uint64_t &rng) {
   return onb_local_vec(uvw, D3(cs * sq, sn * sq, z));
 }
 
-RT_DEV double cosine_pdf_value(const Onb &uvw, d3 direction) {  // pdf.rs:159-162
-  double cosine_theta = dot(normalized(direction), uvw.w);
+RT_DEV double cosine_pdf_value(const Onb &uvw, d3 renormalized) {  // pdf.rs:159-162, argument = direction.normalized()
+  double cosine_theta = dot(renormalized, uvw.w);
   return fmax(0.0, cosine_theta / kPi);
 }
 
@@ -517,12 +519,13 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
         if (pick < 0.5) dir = attractor_generate(sc, point, rng);
         else dir = onb_local_vec(uvw, random_cosine_direction(rng));
         nd = normalized(dir);
-        spdf = cosine_pdf_value(uvw, nd);
-        pdf_val = 0.5 * attractor_pdf_value(sc, point, nd) + (1. - 0.5) * spdf;
+        d3 nn = normalized(nd);  // both densities normalise the (already unit) direction once more
+        spdf = cosine_pdf_value(uvw, nn);
+        pdf_val = 0.5 * attractor_pdf_value(sc, point, nd, nn) + (1. - 0.5) * spdf;
       } else {
         dir = onb_local_vec(uvw, random_cosine_direction(rng));
         nd = normalized(dir);
-        spdf = cosine_pdf_value(uvw, nd);
+        spdf = cosine_pdf_value(uvw, normalized(nd));
         pdf_val = spdf;
       }
       // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419).
