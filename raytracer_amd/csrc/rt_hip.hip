@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{24, 16, kMaxLeafQueue};
+  ExtendTuning t{40, 16, kMaxLeafQueue};
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
