@@ -187,13 +187,14 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
 // * Per-lane stacks and leaf queues live in LDS, laid out [level][lane].
 extern __shared__ uint32_t g_lds[];
 
-constexpr uint32_t kClaim = 256;
+constexpr uint32_t kClaim = 512;
 constexpr uint32_t kNoRay = 0xffffffffu;
 
 struct ExtendTuning {
   int refill;    // refill idle lanes when at least this many are idle
   int node_min;  // run the queued leaf tests when fewer lanes than this have node work
   int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
+  int claim;     // rays a wave takes from a region's counter at a time
 };
 
 template <bool QUIRK, bool COUNT, bool GRID>
@@ -228,12 +229,12 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         uint32_t r_count = counts[r * kCounterStride];
         uint32_t off = r_count;
         if (*(volatile uint32_t *)&work[r * kCounterStride] < r_count) {
-          if (lane == 0) off = atomicAdd(&work[r * kCounterStride], kClaim);
+          if (lane == 0) off = atomicAdd(&work[r * kCounterStride], (uint32_t)tune.claim);
           off = __shfl(off, 0);
         }
         if (off < r_count) {
           w_next = r * q.cap + off;
-          w_end = r * q.cap + min(off + kClaim, r_count);
+          w_end = r * q.cap + min(off + (uint32_t)tune.claim, r_count);
         } else if (++region_try == kRegions) {
           dry = true;
         }
@@ -304,10 +305,11 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 16, kMaxLeafQueue};
+  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim};
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
+  if (const char *e = getenv("RT_HIP_CLAIM")) t.claim = std::max(64, std::min(1 << 16, atoi(e)));
   return t;
 }
 
@@ -320,7 +322,7 @@ static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t 
   static const ExtendTuning tune = extend_tuning();
   // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
   // a whole number of them per region
-  int64_t claims = (n_upper + kClaim - 1) / kClaim;
+  int64_t claims = (n_upper + tune.claim - 1) / tune.claim;
   int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, 256 * 32));
   dim3 g(grid), b(64);
   size_t lds = extend_lds_bytes(sc);
