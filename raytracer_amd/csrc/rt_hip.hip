@@ -1584,7 +1584,9 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       int64_t np = (int64_t)ns * S * G;
       HIP_TRY(hipMemsetAsync(qcounts, 0, (n_counters - kCounterStride) * sizeof(uint32_t), st));
       int g = grid_for(np, block, max_blocks);
-      int g_shade = std::max(kRegions, g / kRegions * kRegions);
+      // k_shade: a whole number of workgroups per region, and many more of them than fit the
+      // chip at once -- short workgroups even out the uneven cost of the material branches
+      int g_shade = (int)std::min<int64_t>(256 * 64, (np / block / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
       hipLaunchKernelGGL(k_generate, dim3(g), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
       HIP_TRY(mark_end());
