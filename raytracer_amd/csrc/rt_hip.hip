@@ -21,6 +21,7 @@
 // Path state lives in SoA queues in HBM; every array is indexed so that a
 // wave touches consecutive addresses.
 #include <hip/hip_runtime.h>
+#include <hipcub/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -108,7 +109,29 @@ struct RenderParams {
   uint64_t seed;
   int32_t n_pix;  // pixels in the shard
   int32_t flags;
+  // order of the pixels in the active list (see pixel_of_key)
+  uint32_t tiles_x, n_tiles, tile_mult, tile_inv;
 };
+
+// The active list holds sort keys, not pixel numbers, and is kept sorted.  A key names an 8x8
+// tile of the shard and a pixel in it: key = rank(tile) * 64 + (row % 8) * 8 + (x % 8), where
+// rank(tile) = tile * tile_mult mod n_tiles scatters consecutive tiles over the whole list.
+// Neighbouring entries are therefore neighbouring pixels (coherent rays within a wave and a
+// claim), while every contiguous slice of the list -- a queue region, served by one XCD and by a
+// fixed set of k_shade workgroups -- is a fair sample of the image: cheap and costly parts of
+// the picture do not pile up in different regions.
+__device__ __forceinline__ uint32_t pixel_of_key(const RenderParams &rp, uint32_t key) {
+  uint32_t within = key & 63u, rank = key >> 6;
+  uint32_t tile = (uint32_t)(((uint64_t)rank * rp.tile_inv) % rp.n_tiles);
+  uint32_t ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
+  return (ty * 8u + (within >> 3)) * (uint32_t)rp.width + tx * 8u + (within & 7u);
+}
+__device__ __forceinline__ uint32_t key_of_pixel(const RenderParams &rp, uint32_t p) {
+  uint32_t row = p / (uint32_t)rp.width, x = p - row * (uint32_t)rp.width;
+  uint32_t tile = (row >> 3) * rp.tiles_x + (x >> 3);
+  uint32_t rank = (uint32_t)(((uint64_t)tile * rp.tile_mult) % rp.n_tiles);
+  return rank * 64u + (row & 7u) * 8u + (x & 7u);
+}
 
 // XCD-aware block order: the dispatcher deals consecutive workgroups
 // round-robin over the 8 XCDs, so workgroups b and b+8 share an L2.  Map the
@@ -139,7 +162,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     int32_t i = (int32_t)(j % rp.S);
     int64_t sg = j / rp.S;
     int32_t g = (int32_t)(sg % G), slot = (int32_t)(sg / G);
-    uint32_t p = active[slot];
+    uint32_t p = pixel_of_key(rp, active[slot]);
     int32_t x = (int32_t)(p % (uint32_t)rp.width);
     int32_t y = rp.row_first + (int32_t)(p / (uint32_t)rp.width) * rp.row_stride;
     // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
@@ -610,14 +633,15 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
   double2 *tile = tile_all[threadIdx.x >> 6];
   for (int32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += gridDim.x * blockDim.x) {
     bool again = false;
-    uint32_t p = 0;
+    uint32_t p = 0, key = 0;
     unsigned long long my_rays = 0, my_samples = 0;
     const bool valid = slot < n_slots;
     const int32_t slot0 = slot - (int32_t)lane;  // first slot of this wave
     double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0;
     double *ps = sums;
     if (valid) {
-      p = active[slot];
+      key = active[slot];
+      p = pixel_of_key(rp, key);
       ps = sums + p;
       if (batch0) {
         sr = ps[0]; sg = ps[np]; sb = ps[2 * np]; sw = ps[3 * np];
@@ -807,13 +831,13 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
       uint32_t base = 0;
       if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
       base = __shfl(base, leader);
-      if (again) next_active[base + prefix] = p;
+      if (again) next_active[base + prefix] = key;
     }
   }
 }
 
-__global__ void k_iota(uint32_t *a, uint32_t n) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = i;
+__global__ void k_all_keys(RenderParams rp, uint32_t *a, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = key_of_pixel(rp, i);
 }
 
 // ============================================== primary hits / caller rays
@@ -1011,6 +1035,30 @@ RenderParams make_params(const RtConfig *cfg) {
   rp.seed = cfg->seed;
   rp.n_pix = shard_rows(cfg) * cfg->img_width;
   rp.flags = cfg->flags;
+  // tile order of the active list: a multiplier near 0.618 * n_tiles, coprime to n_tiles, and its inverse
+  rp.tiles_x = (uint32_t)(cfg->img_width + 7) / 8u;
+  rp.n_tiles = rp.tiles_x * ((uint32_t)(shard_rows(cfg) + 7) / 8u);
+  auto gcd = [](uint64_t a, uint64_t b) {
+    while (b) {
+      uint64_t t = a % b;
+      a = b;
+      b = t;
+    }
+    return a;
+  };
+  uint64_t m = std::max<uint64_t>(1, (uint64_t)(0.6180339887 * rp.n_tiles));
+  while (gcd(m, rp.n_tiles) != 1) m++;
+  m %= rp.n_tiles;
+  if (rp.n_tiles == 1) m = 0;
+  // inverse of m modulo n_tiles (extended Euclid)
+  int64_t t0 = 0, t1 = 1, r0 = rp.n_tiles, r1 = (int64_t)m;
+  while (r1 != 0) {
+    int64_t qq = r0 / r1, tt = t0 - qq * t1, rr = r0 - qq * r1;
+    t0 = t1; t1 = tt; r0 = r1; r1 = rr;
+  }
+  if (t0 < 0) t0 += rp.n_tiles;
+  rp.tile_mult = (uint32_t)m;
+  rp.tile_inv = rp.n_tiles == 1 ? 0u : (uint32_t)t0;
   return rp;
 }
 
@@ -1534,9 +1582,21 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     if (out->samples) HIP_TRY(sc.alloc(&po.samples, (size_t)n_pix));
   }
 
+  // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
+  // the list is put back into raster order after every round that drops pixels, because the
+  // order of the pixels is the order of the rays in every queue, and neighbouring pixels send
+  // rays through the same nodes.
+  size_t sort_bytes = 0;
+  int sort_bits = 1;
+  while (sort_bits < 32 && (1ll << sort_bits) < (int64_t)rp.n_tiles * 64) sort_bits++;
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, active[0], active[1], n_pix, 0, sort_bits, st));
+  void *sort_tmp = nullptr;
+  HIP_TRY(sc.raw(&sort_tmp, sort_bytes));
+
   const int block = 256;
   const int max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups
-  hipLaunchKernelGGL(k_iota, dim3(grid_for(n_pix, block, max_blocks)), dim3(block), 0, st, active[0], (uint32_t)n_pix);
+  hipLaunchKernelGGL(k_all_keys, dim3(grid_for(n_pix, block, max_blocks)), dim3(block), 0, st, rp, active[1], (uint32_t)n_pix);
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, active[1], active[0], (int)n_pix, 0, sort_bits, st));
 
   struct TimedLaunch {
     hipEvent_t a, b;
@@ -1619,8 +1679,12 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       if ((uint64_t)stopped * 20 <= n_active) group = std::min(max_group, std::max(rounds == 0 ? first_jump : 1, group * 2));
       else if ((uint64_t)stopped * 5 > n_active) group = std::max(1, group / 2);
     }
+    if (stopped == 0) {
+      // nothing dropped: the list in use is still right, and still in raster order
+    } else if (next > 0) {
+      HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, active[cur ^ 1], active[cur], (int)next, 0, sort_bits, st));
+    }
     n_active = next;
-    cur ^= 1;
     b += G;
     rounds++;
   }
