@@ -69,6 +69,9 @@ constexpr int32_t kFlagReferenceVisitRule = RT_FLAG_REFERENCE_VISIT_RULE;
 // life, every region has its own append counter (one global atomic word serves
 // only ~90 M appends/s, far less than the kernels produce), and region r is
 // always processed by workgroups with blockIdx % kRegions == r, i.e. by one XCD.
+#ifndef RT_TILE_LOG
+#define RT_TILE_LOG 3
+#endif
 constexpr int kRegions = 64;
 constexpr int kCounterStride = 32;  // uint32 words between two counters: one 128-byte line each
 
@@ -120,17 +123,18 @@ struct RenderParams {
 // claim), while every contiguous slice of the list -- a queue region, served by one XCD and by a
 // fixed set of k_shade workgroups -- is a fair sample of the image: cheap and costly parts of
 // the picture do not pile up in different regions.
+constexpr uint32_t kTileLog = RT_TILE_LOG, kTileSide = 1u << kTileLog, kTileMask = kTileSide - 1u;
 __device__ __forceinline__ uint32_t pixel_of_key(const RenderParams &rp, uint32_t key) {
-  uint32_t within = key & 63u, rank = key >> 6;
+  uint32_t within = key & (kTileSide * kTileSide - 1u), rank = key >> (2 * kTileLog);
   uint32_t tile = (uint32_t)(((uint64_t)rank * rp.tile_inv) % rp.n_tiles);
   uint32_t ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
-  return (ty * 8u + (within >> 3)) * (uint32_t)rp.width + tx * 8u + (within & 7u);
+  return (ty * kTileSide + (within >> kTileLog)) * (uint32_t)rp.width + tx * kTileSide + (within & kTileMask);
 }
 __device__ __forceinline__ uint32_t key_of_pixel(const RenderParams &rp, uint32_t p) {
   uint32_t row = p / (uint32_t)rp.width, x = p - row * (uint32_t)rp.width;
-  uint32_t tile = (row >> 3) * rp.tiles_x + (x >> 3);
+  uint32_t tile = (row >> kTileLog) * rp.tiles_x + (x >> kTileLog);
   uint32_t rank = (uint32_t)(((uint64_t)tile * rp.tile_mult) % rp.n_tiles);
-  return rank * 64u + (row & 7u) * 8u + (x & 7u);
+  return (rank << (2 * kTileLog)) + ((row & kTileMask) << kTileLog) + (x & kTileMask);
 }
 
 // XCD-aware block order: the dispatcher deals consecutive workgroups
@@ -1036,8 +1040,8 @@ RenderParams make_params(const RtConfig *cfg) {
   rp.n_pix = shard_rows(cfg) * cfg->img_width;
   rp.flags = cfg->flags;
   // tile order of the active list: a multiplier near 0.618 * n_tiles, coprime to n_tiles, and its inverse
-  rp.tiles_x = (uint32_t)(cfg->img_width + 7) / 8u;
-  rp.n_tiles = rp.tiles_x * ((uint32_t)(shard_rows(cfg) + 7) / 8u);
+  rp.tiles_x = ((uint32_t)cfg->img_width + kTileMask) >> kTileLog;
+  rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + kTileMask) >> kTileLog);
   auto gcd = [](uint64_t a, uint64_t b) {
     while (b) {
       uint64_t t = a % b;
@@ -1588,7 +1592,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   // rays through the same nodes.
   size_t sort_bytes = 0;
   int sort_bits = 1;
-  while (sort_bits < 32 && (1ll << sort_bits) < (int64_t)rp.n_tiles * 64) sort_bits++;
+  while (sort_bits < 32 && (1ll << sort_bits) < ((int64_t)rp.n_tiles << (2 * kTileLog))) sort_bits++;
   HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, active[0], active[1], n_pix, 0, sort_bits, st));
   void *sort_tmp = nullptr;
   HIP_TRY(sc.raw(&sort_tmp, sort_bytes));
