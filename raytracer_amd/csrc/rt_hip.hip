@@ -72,7 +72,7 @@ constexpr int32_t kFlagReferenceVisitRule = RT_FLAG_REFERENCE_VISIT_RULE;
 #ifndef RT_TILE_LOG
 #define RT_TILE_LOG 3
 #endif
-constexpr int kRegions = 64;
+constexpr int kRegions = 32;
 constexpr int kCounterStride = 32;  // uint32 words between two counters: one 128-byte line each
 
 struct PathQueue {
