@@ -308,6 +308,24 @@ def test_render_is_deterministic_and_tiling_independent():
             assert np.array_equal(s[k], a[k][first::3]), (k, first)
 
 
+@pytest.mark.parametrize("width,height,stride", [(1, 1, 1), (7, 3, 1), (9, 17, 2), (65, 8, 3), (8, 65, 1)])
+def test_odd_image_shapes_match_the_oracle(width, height, stride):
+    """Images that are not whole tiles, single pixels, shards with fewer rows than a tile."""
+    ri = c1(width=width, height=height, batch=4, max_batches=6, min_batches=1)
+    for first in range(stride):
+        cfg = ri.config.copy()
+        cfg.row_first, cfg.row_stride = first, stride
+        if cfg.n_rows() <= 0:
+            continue
+        out_g, st_g = ri.resident(0).render(cfg)
+        out_o, st_o = oracle.render(ri.scene, cfg, 4)
+        assert out_g["linear"].shape == out_o["linear"].shape
+        assert np.array_equal(out_g["samples"], out_o["samples"])
+        frac, rmse, worst = _image_checks(out_g, st_g, out_o, st_o, cfg)
+        assert frac >= 0.97 or worst < 1e-6, (frac, worst)
+        assert st_g.samples == st_o.samples
+
+
 def test_early_termination_flag_does_not_change_pixels():
     ri = c1(width=32, height=32, batch=16)
     cfg = ri.config.copy()
