@@ -2,10 +2,11 @@
 // include/rt_hip.h: a wavefront path tracer that replaces the reference's
 // per-row loop (/root/reference/src/render/integrator.rs:226-339).
 //
-// Pipeline per batch round (one round = one `b` iteration of
-// integrator.rs:279 for every still-active pixel):
+// Pipeline per round (one round = several consecutive `b` iterations of
+// integrator.rs:279 for every still-active pixel; batches traced beyond a
+// pixel's stopping batch are dropped):
 //
-//   k_generate    one lane per (active pixel, sample i): Sobol offset,
+//   k_generate    one lane per (active pixel, batch, sample i): Sobol offset,
 //                 Mitchell weight, camera ray, per-path RNG stream
 //                 (integrator.rs:284-296, camera.rs:95-120)
 //   per bounce:
@@ -17,6 +18,8 @@
 //                 (integrator.rs:305-326, stats.rs), compaction of the
 //                 unconverged pixels, final clamp + gamma + heat-map
 //                 (integrator.rs:331-337)
+//   radix sort    of the surviving pixels' keys: the active list stays in its
+//                 scattered-tile order (pixel_of_key)
 //
 // Path state lives in SoA queues in HBM; every array is indexed so that a
 // wave touches consecutive addresses.
