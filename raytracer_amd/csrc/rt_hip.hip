@@ -117,27 +117,30 @@ struct RenderParams {
   int32_t flags;
   // order of the pixels in the active list (see pixel_of_key)
   uint32_t tiles_x, n_tiles, tile_mult, tile_inv;
+  uint32_t tile_wlog, tile_hlog;  // a tile is 2^wlog pixels wide and 2^hlog rows of the shard high (64 pixels)
 };
 
-// The active list holds sort keys, not pixel numbers, and is kept sorted.  A key names an 8x8
-// tile of the shard and a pixel in it: key = rank(tile) * 64 + (row % 8) * 8 + (x % 8), where
+// The active list holds sort keys, not pixel numbers, and is kept sorted.  A key names a 64-pixel
+// tile of the shard and a pixel in it (8x8 for a whole image; wider and flatter when the shard
+// holds every n-th row only, so that the tile stays compact in the image):
+// key = rank(tile) * 64 + (row % h) * w + (x % w), where
 // rank(tile) = tile * tile_mult mod n_tiles scatters consecutive tiles over the whole list.
 // Neighbouring entries are therefore neighbouring pixels (coherent rays within a wave and a
 // claim), while every contiguous slice of the list -- a queue region, served by one XCD and by a
 // fixed set of k_shade workgroups -- is a fair sample of the image: cheap and costly parts of
 // the picture do not pile up in different regions.
-constexpr uint32_t kTileLog = RT_TILE_LOG, kTileSide = 1u << kTileLog, kTileMask = kTileSide - 1u;
+constexpr uint32_t kTileLog = RT_TILE_LOG;  // log2 of the side of a square tile; a tile has 4^kTileLog pixels
 __device__ __forceinline__ uint32_t pixel_of_key(const RenderParams &rp, uint32_t key) {
-  uint32_t within = key & (kTileSide * kTileSide - 1u), rank = key >> (2 * kTileLog);
+  uint32_t within = key & ((1u << (2 * kTileLog)) - 1u), rank = key >> (2 * kTileLog);
   uint32_t tile = (uint32_t)(((uint64_t)rank * rp.tile_inv) % rp.n_tiles);
   uint32_t ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
-  return (ty * kTileSide + (within >> kTileLog)) * (uint32_t)rp.width + tx * kTileSide + (within & kTileMask);
+  return ((ty << rp.tile_hlog) + (within >> rp.tile_wlog)) * (uint32_t)rp.width + (tx << rp.tile_wlog) + (within & ((1u << rp.tile_wlog) - 1u));
 }
 __device__ __forceinline__ uint32_t key_of_pixel(const RenderParams &rp, uint32_t p) {
   uint32_t row = p / (uint32_t)rp.width, x = p - row * (uint32_t)rp.width;
-  uint32_t tile = (row >> kTileLog) * rp.tiles_x + (x >> kTileLog);
+  uint32_t tile = (row >> rp.tile_hlog) * rp.tiles_x + (x >> rp.tile_wlog);
   uint32_t rank = (uint32_t)(((uint64_t)tile * rp.tile_mult) % rp.n_tiles);
-  return (rank << (2 * kTileLog)) + ((row & kTileMask) << kTileLog) + (x & kTileMask);
+  return (rank << (2 * kTileLog)) + ((row & ((1u << rp.tile_hlog) - 1u)) << rp.tile_wlog) + (x & ((1u << rp.tile_wlog) - 1u));
 }
 
 // XCD-aware block order: the dispatcher deals consecutive workgroups
@@ -1043,8 +1046,12 @@ RenderParams make_params(const RtConfig *cfg) {
   rp.n_pix = shard_rows(cfg) * cfg->img_width;
   rp.flags = cfg->flags;
   // tile order of the active list: a multiplier near 0.618 * n_tiles, coprime to n_tiles, and its inverse
-  rp.tiles_x = ((uint32_t)cfg->img_width + kTileMask) >> kTileLog;
-  rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + kTileMask) >> kTileLog);
+  // rows of the shard are row_stride image rows apart: trade tile height for width accordingly
+  rp.tile_hlog = kTileLog;
+  for (int s = cfg->row_stride; s > 1 && rp.tile_hlog > 0; s >>= 1) rp.tile_hlog--;
+  rp.tile_wlog = 2 * kTileLog - rp.tile_hlog;
+  rp.tiles_x = ((uint32_t)cfg->img_width + (1u << rp.tile_wlog) - 1u) >> rp.tile_wlog;
+  rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + (1u << rp.tile_hlog) - 1u) >> rp.tile_hlog);
   auto gcd = [](uint64_t a, uint64_t b) {
     while (b) {
       uint64_t t = a % b;
