@@ -616,7 +616,7 @@ struct PixelOutputs {
   double *pixels, *sample_pixels, *linear;
   uint32_t *samples;
 };
-constexpr int kAccChunk = 8;  // batches k_accumulate evaluates together
+constexpr int kAccChunk = 4;  // batches k_accumulate evaluates together
 
 // One lane per active pixel.  Processes the G batches of the round in order,
 // exactly as the `'batch` loop of integrator.rs:279-328 would: ordered sum of
