@@ -123,6 +123,24 @@ def test_triangle_hit_culls_back_faces_and_is_inclusive():
     assert oracle.triangle_hit(tri, (0.75, 0.75, 1.0), (0, 0, -1), 0.0001, 1e308) is None   # u + v > 1
 
 
+# ----------------------------------------------------------- render/interval.rs:42-82
+def test_interval_known_answers():
+    """Interval has no type of its own here: its three operations live in the box merge, the
+    box padding and the primitives' range check.  The reference's own cases, replayed there."""
+    # new_from_intervals((0.1, 0.2), (0.3, -0.4)) == (0.1, 0.2), interval.rs:54-62 -- per axis of Aabb::merge
+    m = host_ref.Aabb.merge(host_ref.Aabb((0.1, 0.1, 0.1), (0.2, 0.2, 0.2)), host_ref.Aabb((0.3, 0.3, 0.3), (-0.4, -0.4, -0.4)))
+    assert m.min == (0.1, 0.1, 0.1) and m.max == (0.2, 0.2, 0.2)
+    # size() == max - min, interval.rs:65-68; expand(delta) moves each end by delta / 2, interval.rs:71-75
+    # (Aabb::pad expands an axis thinner than 1e-4 by 1e-4, aabb.rs:122-152)
+    b = host_ref.Aabb((0.1, 0.0, 0.0), (0.1, 1.0, 1.0)).pad()
+    assert b.min[0] == 0.1 - 0.0001 / 2.0 and b.max[0] == 0.1 + 0.0001 / 2.0 and (b.min[1], b.max[1]) == (0.0, 1.0)
+    # contains(): both ends inclusive, interval.rs:78-82 -- the [1, 2] interval of the reference's test as a ray interval
+    tri = _tri((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    assert oracle.triangle_hit(tri, (0.25, 0.25, 1.5), (0, 0, -1), 1.0, 2.0) == 1.5
+    assert oracle.triangle_hit(tri, (0.25, 0.25, 2.5), (0, 0, -1), 1.0, 2.0) is None
+    assert oracle.triangle_hit(tri, (0.25, 0.25, 2.0), (0, 0, -1), 1.0, 2.0) == 2.0
+
+
 def test_quad_hit_and_pdf():
     quad = _quad((343.0, 554.0, 332.0), (-130.0, 0.0, 0.0), (0.0, 0.0, -105.0))
     assert quad.area == 13650.0
