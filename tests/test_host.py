@@ -133,6 +133,31 @@ def test_aabb_known_answers_from_reference_tests():
     assert host_ref.Aabb.from_points((0.0, 0.0, 0.0), (2.0, 2.0, 2.0)).largest_axis() == 2
 
 
+def test_sphere_boxes_known_answers_from_reference_tests():
+    """elements/tests.rs:75-99: Sphere::new((0,0,0), 1) is boxed by [-1, 1]^3 and
+    Sphere::new((2,1,-1), 1) by x [1,3], y [0,2], z [-2,0]; tests.rs:67-72: centre and radius kept."""
+    sc = {"camera": scenes.camera(), "elements": [scenes.sphere((0, 0, 0), 1.0, scenes.lambertian(1, 1, 1), attractor=False),
+                                                   scenes.sphere((2, 1, -1), 1.0, scenes.lambertian(1, 1, 1), attractor=False),
+                                                   scenes.sphere((1, 2, -1), 2.0, scenes.lambertian(1, 1, 1), attractor=False)]}
+    ri = RenderIntegrator.new(sc, scenes.config(8, 8, 1, 1, 1)).prepare()
+    assert ri.element_bbox(0) == ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+    assert ri.element_bbox(1) == ((1.0, 0.0, -2.0), (3.0, 2.0, 0.0))
+    s2 = ri.scene.contents.spheres[2]
+    assert s2.center.tuple() == (1.0, 2.0, -1.0) and s2.radius == 2.0
+
+
+def test_triangle_record_known_answers_from_reference_tests():
+    """elements/tests.rs:28-39: Triangle::new keeps v0 and the edges to v1 = (0,2,0), v2 = (2,2,0)."""
+    sc = {"camera": scenes.camera(), "elements": [{"JSONTriangle": {"v0": scenes._v(0, 0, 0), "v1": scenes._v(0, 2, 0), "v2": scenes._v(2, 2, 0),
+                                                                     "material": scenes.lambertian(1, 1, 1)}},
+                                                   {"JSONTriangle": {"v0": scenes._v(5, 5, 5), "v1": scenes._v(6, 5, 5), "v2": scenes._v(5, 6, 5),
+                                                                     "material": scenes.lambertian(1, 1, 1)}}]}
+    ri = RenderIntegrator.new(sc, scenes.config(8, 8, 1, 1, 1)).prepare()
+    t = ri.scene.contents.triangles[0]
+    assert t.v0.tuple() == (0.0, 0.0, 0.0) and t.v0v1.tuple() == (0.0, 2.0, 0.0) and t.v0v2.tuple() == (2.0, 2.0, 0.0)
+    assert t.normal.tuple() == (0.0, 0.0, -1.0)  # (v1 - v0) x (v2 - v0), normalised (triangle.rs:58)
+
+
 def test_obj_loader_fan_and_slashes(tmp_path):
     p = tmp_path / "m.obj"
     p.write_text("# c\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1 4/1/1\nf -4 -3 -2\n")
