@@ -268,3 +268,40 @@ def scene_soup(n_triangles, seed=12345, defocus_angle=0.6, focus_dist=1000.0):
     """Cornell room + quad light (attractor) filled with a triangle soup, thin-lens camera."""
     els = soup_elements(n_triangles, seed) + cornell_elements()
     return {"camera": camera(defocus_angle=defocus_angle, focus_dist=focus_dist), "elements": els}
+
+
+def materialize_soup(directory, n_triangles, width, height, batch=16, max_batches=4, min_batches=2, seed=12345):
+    """The triangle-soup scene at sizes JSON elements cannot carry: the soup of soup_elements
+    (same distributions) written as three OBJ files, one per material class -- Lambertian
+    (0.55, 0.55, 0.55), Metal (0.7, 0.7, 0.7) fuzz 0.15, Dielectric 1.5 -- because an OBJ element
+    has one material.  Returns the scene and config JSON paths."""
+    os.makedirs(directory, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    c = rng.uniform(20.0, 535.0, size=(n_triangles, 3))
+    e1 = rng.uniform(-4.0, 4.0, size=(n_triangles, 3))
+    e2 = rng.uniform(-4.0, 4.0, size=(n_triangles, 3))
+    kind = rng.uniform(size=n_triangles)
+    v0 = c - (e1 + e2) / 3.0
+    groups = [("lambertian", kind >= 0.2, lambertian(0.55, 0.55, 0.55)), ("metal", (kind >= 0.1) & (kind < 0.2), metal(0.7, 0.7, 0.7, 0.15)),
+              ("glass", kind < 0.1, dielectric(1.5))]
+    els = []
+    for name, mask, material in groups:
+        k = int(mask.sum())
+        if k == 0:
+            continue
+        path = os.path.join(directory, f"soup_{n_triangles}_{name}.obj")
+        if not os.path.exists(path):
+            verts = np.empty((3 * k, 3))
+            verts[0::3], verts[1::3], verts[2::3] = v0[mask], v0[mask] + e1[mask], v0[mask] + e2[mask]
+            faces = np.arange(3 * k).reshape(k, 3)
+            tmp = path + ".tmp"
+            write_obj(tmp, verts, faces)
+            os.replace(tmp, path)
+        els.append(obj_element(path, material))
+    scene = {"camera": camera(defocus_angle=0.6, focus_dist=1000.0), "elements": els + cornell_elements()}
+    scene_path, config_path = os.path.join(directory, "scene_soup.json"), os.path.join(directory, "config_soup.json")
+    with open(scene_path, "w") as f:
+        json.dump(scene, f)
+    with open(config_path, "w") as f:
+        json.dump(config(width, height, batch, max_batches, min_batches), f)
+    return scene_path, config_path
