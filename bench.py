@@ -234,6 +234,7 @@ def main():
             "rays_by_depth_rank0_last_step": rays_by_depth[:cfg.max_depth],
             "host_build_s": t_host,
             "upload_s": t_upload,
+            "time_to_image_with_load_build_upload_s": elapsed / args.steps + t_host + t_upload,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_extend",
