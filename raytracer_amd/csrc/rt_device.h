@@ -101,6 +101,11 @@ struct DevScene {
   int32_t stack_depth;  // LDS stack entries per lane
   int32_t quirk;        // 1 when the walk must follow the reference's visit rule step by step: some child box
                         // does not contain the primitives below it, or the nodes do not form a tree
+  // When the only offenders are a few primitives that stick out of their own leaf boxes, `danger` holds
+  // their true bounds (min xyz, max xyz per box): a ray that misses all of them cannot hit any of those
+  // primitives, so for it the reference's result is the plain closest hit and the fast walk applies.
+  const double *danger;
+  int32_t n_danger;
   RtCamera camera;
 };
 
@@ -341,6 +346,7 @@ struct Hit {
 
 constexpr uint32_t kDone = 0xffffffffu;  // no node left (has the leaf bit set on purpose)
 constexpr uint32_t kWait = 0xfffffffeu;  // QUIRK: a pop is waiting for deferred leaf tests
+constexpr uint32_t kPending = 0xfffffffdu;  // hit buffer: the ray is left to the reference-rule pass
 constexpr int kMaxLeafQueue = 4;         // deferred leaf tests per lane
 
 // f32 copy of a ray for the box tests.  The origin is widened by its own
@@ -435,6 +441,23 @@ RT_DEV bool slab_hit_q(float qminx, float qminy, float qminz, float qmaxx, float
   float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
   tn_out = tn;
   return tn <= fminf(tf, tmax);
+}
+
+// Does the ray come near one of the out-of-box primitives?  Slab test in f64 on their true bounds
+// (padded at upload); passes whenever the ray could touch the box.
+RT_DEV bool hits_danger_box(const DevScene &sc, d3 o, d3 d) {
+  d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  bool any = false;
+  for (int i = 0; i < sc.n_danger; i++) {
+    const double *b = sc.danger + 6 * i;
+    double t1 = (b[0] - o.x) * inv.x, t2 = (b[3] - o.x) * inv.x;
+    double t3 = (b[1] - o.y) * inv.y, t4 = (b[4] - o.y) * inv.y;
+    double t5 = (b[2] - o.z) * inv.z, t6 = (b[5] - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+    double tf = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+    any = any || !(tn > tf * (1.0 + 1e-12) + 1e-300) || tn != tn || tf != tf;  // NaN (0 * inf) counts as a hit
+  }
+  return any;
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

@@ -34,6 +34,7 @@
 #include <cstring>
 #include <atomic>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -228,6 +229,7 @@ struct ExtendTuning {
   int node_min;  // run the queued leaf tests when fewer lanes than this have node work
   int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
   int claim;     // rays a wave takes from a region's counter at a time
+  int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
 template <bool QUIRK, bool COUNT, bool GRID>
@@ -282,6 +284,14 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           if (GRID) fq = make_rayq(sc, ro, rd);
           else f = make_rayf(ro, rd);
           trav_begin(sc, tv);
+          if (tune.pass == 1 && hits_danger_box(sc, ro, rd)) {
+            hits.ref[j] = kPending;
+            j = kNoRay;
+            tv.cur = kDone;
+          } else if (tune.pass == 2 && hits.ref[j] != kPending) {
+            j = kNoRay;
+            tv.cur = kDone;
+          }
         }
         w_next = min(w_end, w_next + (uint32_t)n_idle);
         n_idle = __popcll(__ballot(j == kNoRay));
@@ -338,7 +348,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim};
+  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 0};
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
@@ -350,9 +360,14 @@ static size_t extend_lds_bytes(const DevScene &sc) { return (size_t)(sc.stack_de
 
 // `counts` = entries per region, `work` = claim counters per region (zeroed by the caller); both
 // kCounterStride words apart.
-static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t n_upper, hipStream_t st, PathQueue q,
-                          const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
-  static const ExtendTuning tune = extend_tuning();
+// Which walk a query takes: 0 the order-free one, 1 the reference's visit rule for every ray,
+// 2 both -- the order-free walk for the rays that stay clear of the out-of-box primitives and
+// the reference's rule for the others.
+static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int pass, int64_t n_upper, hipStream_t st, PathQueue q,
+                               const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
+  static const ExtendTuning base = extend_tuning();
+  ExtendTuning tune = base;
+  tune.pass = pass;
   // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
   // a whole number of them per region
   int64_t claims = (n_upper + tune.claim - 1) / tune.claim;
@@ -368,6 +383,18 @@ static void launch_extend(const DevScene &sc, bool quirk, bool counted, int64_t 
   } else {
     if (counted) hipLaunchKernelGGL((k_extend<false, true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
     else hipLaunchKernelGGL((k_extend<false, false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+  }
+}
+
+// `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
+// passes, zeroed by the caller; all kCounterStride words apart.
+static void launch_extend(const DevScene &sc, int mode, bool counted, int64_t n_upper, hipStream_t st, PathQueue q,
+                          const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, uint32_t *work2, unsigned long long *visit_counters) {
+  if (mode == 2) {
+    launch_extend_pass(sc, false, counted, 1, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    launch_extend_pass(sc, true, counted, 2, n_upper, st, q, count_ptr, hits, work2, visit_counters);
+  } else {
+    launch_extend_pass(sc, mode == 1, counted, 0, n_upper, st, q, count_ptr, hits, work, visit_counters);
   }
 }
 
@@ -1085,7 +1112,11 @@ int grid_for(int64_t n, int block, int max_blocks) {
 
 // Children whose box the ray misses are skipped whenever that cannot change a result (every box
 // bounds its contents); otherwise, or on request, the reference's visit rule is followed exactly.
-bool use_quirk(const RtSceneHandle *h, int32_t flags) { return h->dev.quirk || (flags & kFlagReferenceVisitRule); }
+int walk_mode(const RtSceneHandle *h, int32_t flags) {
+  if (flags & kFlagReferenceVisitRule) return 1;
+  if (!h->dev.quirk) return 0;
+  return h->dev.n_danger > 0 ? 2 : 1;
+}
 
 }  // namespace
 
@@ -1206,6 +1237,10 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   // child -- by induction every box then contains everything below it.  (A tree whose boxes
   // bound their contents without being nested fails this test and is merely walked the slow way.)
   std::atomic<bool> nested{true};
+  // Leaf children whose primitive sticks out of the child box, kept apart from boxes that are not
+  // nested: if they are few, only the rays that come near them need the reference's rule.
+  std::vector<int32_t> stray_leaves;
+  std::mutex stray_mutex;
   {
     struct B { double mn[3], mx[3]; };
     auto grow = [](B &b, double x, double y, double z) {
@@ -1258,15 +1293,67 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     };
     parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
       bool ok = true;
+      std::vector<int32_t> mine;
       for (size_t i = begin; i < end && ok; i++) {
         const RtNode &n = s->nodes[i];
         if (n.is_leaf || depth[i] < 0) continue;
-        ok = inside(content_of(n.child_l_index), n.child_l_min, n.child_l_max) && inside(content_of(n.child_r_index), n.child_r_min, n.child_r_max);
+        const int32_t child[2] = {n.child_l_index, n.child_r_index};
+        const double *mn[2] = {n.child_l_min, n.child_r_min}, *mx[2] = {n.child_l_max, n.child_r_max};
+        for (int c = 0; c < 2 && ok; c++) {
+          if (inside(content_of(child[c]), mn[c], mx[c])) continue;
+          if (s->nodes[child[c]].is_leaf && mine.size() < 64) mine.push_back(child[c]);
+          else ok = false;
+        }
       }
       if (!ok) nested.store(false, std::memory_order_relaxed);
+      if (!mine.empty()) {
+        std::lock_guard<std::mutex> lock(stray_mutex);
+        stray_leaves.insert(stray_leaves.end(), mine.begin(), mine.end());
+      }
     });
   }
-  bool boxes_bound_contents = nested.load();
+  // true bounds of the stray primitives (a root that is a leaf has no box to stick out of)
+  constexpr size_t kMaxDanger = 16;
+  std::vector<double> danger;
+  if (nested.load() && !stray_leaves.empty() && stray_leaves.size() <= kMaxDanger) {
+    for (int32_t leaf : stray_leaves) {
+      RtElementRef e = s->elements[s->nodes[leaf].element_index];
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      auto add = [&](double x, double y, double z) {
+        const double p[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) lo[a] = std::fmin(lo[a], p[a]), hi[a] = std::fmax(hi[a], p[a]);
+      };
+      if (e.kind == RT_PRIM_TRIANGLE) {
+        const RtTriangle &t = s->triangles[e.index];
+        add(t.v0.x, t.v0.y, t.v0.z);
+        add(t.v0.x + t.v0v1.x, t.v0.y + t.v0v1.y, t.v0.z + t.v0v1.z);
+        add(t.v0.x + t.v0v2.x, t.v0.y + t.v0v2.y, t.v0.z + t.v0v2.z);
+      } else if (e.kind == RT_PRIM_QUAD) {
+        const RtQuad &qd = s->quads[e.index];
+        for (int cu = 0; cu < 2; cu++)
+          for (int cv = 0; cv < 2; cv++) add(qd.q.x + cu * qd.u.x + cv * qd.v.x, qd.q.y + cu * qd.u.y + cv * qd.v.y, qd.q.z + cu * qd.u.z + cv * qd.v.z);
+      } else {
+        const RtSphere &sp = s->spheres[e.index];
+        double rad = std::fabs(sp.radius);
+        add(sp.center.x - rad, sp.center.y - rad, sp.center.z - rad);
+        add(sp.center.x + rad, sp.center.y + rad, sp.center.z + rad);
+      }
+      bool finite = true;
+      for (int a = 0; a < 3; a++) {
+        double pad = 1e-9 * (std::fabs(lo[a]) + std::fabs(hi[a])) + 1e-9;  // the hit test accepts points a rounding off the plane
+        lo[a] -= pad;
+        hi[a] += pad;
+        finite = finite && std::isfinite(lo[a]) && std::isfinite(hi[a]);
+      }
+      if (!finite) {
+        danger.clear();
+        break;
+      }
+      danger.insert(danger.end(), lo, lo + 3);
+      danger.insert(danger.end(), hi, hi + 3);
+    }
+  }
+  bool single_position = true;  // every reachable node has one parent, every element one leaf
   lap("box containment");
   // The reference's leaf order (depth-first, left child first) decides exact ties between
   // primitives; the reordering traversal needs it per element.  An element named by more than
@@ -1286,7 +1373,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     int64_t visited = 0;
     while (!todo.empty()) {
       if (++visited > (int64_t)s->n_nodes) {  // some node has two parents
-        boxes_bound_contents = false;
+        single_position = false;
         break;
       }
       int32_t i = todo.back();
@@ -1294,7 +1381,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       const RtNode &n = s->nodes[i];
       if (n.is_leaf) {
         uint32_t &r = leaf_rank_of_element[(size_t)n.element_index];
-        if (r != 0xffffffffu) boxes_bound_contents = false;
+        if (r != 0xffffffffu) single_position = false;
         r = next_rank++;
         place_triangle(n.element_index);
       } else {
@@ -1304,6 +1391,11 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     }
   }
 
+  bool boxes_bound_contents = single_position && nested.load() && stray_leaves.empty();
+  if (!single_position) danger.clear();
+  // every box bounds what lies below it, or the few primitives that do not are fenced by `danger`:
+  // the order-free walk (and its grid nodes) exists for this tree
+  bool fast_walk_exists = boxes_bound_contents || !danger.empty();
   for (int e = 0; e < s->n_elements; e++) place_triangle(e);  // elements no reachable leaf names
   for (uint32_t &slot : tri_slot)
     if (slot == 0xffffffffu) slot = next_tri_slot++;            // triangles no element names
@@ -1340,7 +1432,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   // than a typical box would make every box test pass.
   std::vector<DevNodeQ> nodes_q;
   double grid_min[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
-  if (boxes_bound_contents && !getenv("RT_HIP_NO_GRID")) {
+  if (fast_walk_exists && !getenv("RT_HIP_NO_GRID")) {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool finite = true;
     for (int i = 0; i < s->n_nodes; i++) {
@@ -1501,6 +1593,18 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   h->dev.root = ref_of_node(0);
   h->dev.stack_depth = std::max(max_depth, 1);
   h->dev.quirk = boxes_bound_contents ? 0 : 1;
+  h->dev.danger = nullptr;
+  h->dev.n_danger = 0;
+  if (fast_walk_exists && !boxes_bound_contents) {
+    rc = dev_upload(h, &h->dev.danger, danger);
+    if (rc != RT_OK) {
+      std::string keep = g_error;
+      rt_hip_scene_free(h);
+      g_error = keep;
+      return rc;
+    }
+    h->dev.n_danger = (int32_t)(danger.size() / 6);
+  }
   h->dev.camera = s->camera;
   lap("device copies");
   *out = h;
@@ -1569,13 +1673,15 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   HIP_TRY(sc.alloc(&active[0], n_pix));
   HIP_TRY(sc.alloc(&active[1], n_pix));
   // counters (each on its own 128-byte line): [0] next_count; then per bounce 0..max_depth the
-  // kRegions queue sizes; then per bounce the kRegions work-claim counters of k_extend
+  // kRegions queue sizes; then per bounce the kRegions work-claim counters of k_extend, twice
+  // (a tree with stray primitives is walked in two launches per bounce, each claiming the whole queue)
   const size_t per_bounce = (size_t)kRegions * kCounterStride;
-  const size_t n_counters = kCounterStride + (size_t)(2 * rp.max_depth + 1) * per_bounce;
+  const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
   HIP_TRY(sc.alloc(&counters, n_counters));
   uint32_t *qcounts = counters + kCounterStride;
   uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
-  const bool quirk = use_quirk(h, rp.flags);
+  uint32_t *work2 = work + (size_t)rp.max_depth * per_bounce;
+  const int walk = walk_mode(h, rp.flags);
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
   constexpr int kTotals = RT_MAX_DEPTH_STATS + 6;
@@ -1666,7 +1772,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
         HIP_TRY(mark_begin(0, k));
-        launch_extend(h->dev, quirk, counted, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, totals + RT_MAX_DEPTH_STATS + 1);
+        launch_extend(h->dev, walk, counted, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
+                      totals + RT_MAX_DEPTH_STATS + 1);
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1));
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
@@ -1767,7 +1874,7 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   HIP_TRY(sc.alloc(&d_t, (size_t)n));
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
-  launch_extend(h->dev, use_quirk(h, flags), false, n, h->stream, q, d_counts, hits, work, nullptr);
+  launch_extend(h->dev, walk_mode(h, flags), false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1784,7 +1891,7 @@ static int alloc_ray_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue *
   const size_t entries = (size_t)q->cap * kRegions;
   HIP_TRY(sc.alloc(&q->ox, entries)); HIP_TRY(sc.alloc(&q->oy, entries)); HIP_TRY(sc.alloc(&q->oz, entries));
   HIP_TRY(sc.alloc(&q->dx, entries)); HIP_TRY(sc.alloc(&q->dy, entries)); HIP_TRY(sc.alloc(&q->dz, entries));
-  const size_t words = 2 * (size_t)kRegions * kCounterStride;
+  const size_t words = 3 * (size_t)kRegions * kCounterStride;
   HIP_TRY(sc.alloc(d_counts, words));
   HIP_TRY(hipMemsetAsync(*d_counts, 0, words * sizeof(uint32_t), h->stream));
   return RT_OK;

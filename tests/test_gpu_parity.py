@@ -228,6 +228,29 @@ def test_irregular_visit_rule_with_unbounded_quads():
     assert np.array_equal(pg, po) and np.array_equal(tg, to)
 
 
+def test_two_pass_walk_equals_reference_rule_alone():
+    """Two stray quads: rays clear of their true bounds take the order-free walk, the rest the
+    reference's rule.  Forcing the reference's rule for every ray must change nothing; with more
+    stray primitives than the device keeps bounds for, every ray takes the reference's rule."""
+    from raytracer_amd import RenderIntegrator, abi, scenes
+    ri = _tilted_quad_scene()
+    cfg = ri.config.copy()
+    out_a, st_a = ri.resident(0).render(cfg)
+    cfg.flags = abi.RT_FLAG_REFERENCE_VISIT_RULE
+    out_b, st_b = ri.resident(0).render(cfg)
+    assert np.array_equal(out_a["linear"], out_b["linear"]) and st_a.rays == st_b.rays
+    sc = scenes.scene_c1()
+    rng = np.random.RandomState(5)
+    for _ in range(24):
+        q, u, v = rng.uniform(60, 400, 3), rng.uniform(-60, 60, 3), rng.uniform(-60, 60, 3)
+        sc["elements"].append({"JSONQuad": {"q": scenes._v(*q), "u": scenes._v(*u), "v": scenes._v(*v), "material": scenes.lambertian(0.5, 0.5, 0.5)}})
+    many = RenderIntegrator.new(sc, scenes.config(48, 48, 4, 1, 1)).prepare()
+    o, d = random_rays(100_000, seed=12)
+    pg, tg = many.resident(0).trace_rays(o, d)
+    po, to = oracle.trace_rays(many.scene, o, d)
+    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+
+
 def _image_checks(out_g, st_g, out_o, st_o, cfg, tight=1e-9):
     lin_g, lin_o = out_g["linear"], out_o["linear"]
     close = np.isclose(lin_g, lin_o, rtol=1e-9, atol=tight).all(axis=-1)
