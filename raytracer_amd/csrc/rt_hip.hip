@@ -1400,6 +1400,57 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   for (uint32_t &slot : tri_slot)
     if (slot == 0xffffffffu) slot = next_tri_slot++;            // triangles no element names
   lap("leaf order");
+  // Storage order of the internal nodes.  The reference's preorder puts a node next to its left
+  // child only; once the node array outgrows the caches every visit is a 128-byte line fetched for
+  // one 32-byte record.  For large trees the records are laid out in blocks that share a line: a
+  // block starts at a node and takes in, largest box first (the child a ray is likeliest to enter),
+  // descendants until the line is full; what is left over starts the next blocks.
+  {
+    const char *order_env = getenv("RT_HIP_NODE_ORDER");
+    bool blocks = order_env ? !strcmp(order_env, "blocks") : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)8 << 20);
+    if (blocks && single_position) {
+      constexpr int kPerLine = 128 / (int)sizeof(DevNodeQ);
+      struct Cand { int32_t node; float area; };
+      auto push_children = [&](std::vector<Cand> &f, int32_t i) {
+        const RtNode &n = s->nodes[i];
+        const int32_t c[2] = {n.child_l_index, n.child_r_index};
+        const double *mn[2] = {n.child_l_min, n.child_r_min}, *mx[2] = {n.child_l_max, n.child_r_max};
+        for (int k = 0; k < 2; k++) {
+          if (s->nodes[c[k]].is_leaf) continue;
+          double dx = mx[k][0] - mn[k][0], dy = mx[k][1] - mn[k][1], dz = mx[k][2] - mn[k][2];
+          f.push_back({c[k], (float)(dx * dy + dy * dz + dz * dx)});
+        }
+      };
+      std::fill(internal_index.begin(), internal_index.end(), -1);
+      int32_t next = 0;
+      std::vector<int32_t> roots;
+      std::vector<Cand> frontier;
+      if (!s->nodes[0].is_leaf) roots.push_back(0);
+      while (!roots.empty()) {
+        int32_t r = roots.back();
+        roots.pop_back();
+        int room = kPerLine - next % kPerLine;
+        frontier.clear();
+        internal_index[(size_t)r] = next++;
+        push_children(frontier, r);
+        for (room--; room > 0 && !frontier.empty(); room--) {
+          size_t best = 0;
+          for (size_t k = 1; k < frontier.size(); k++)
+            if (frontier[k].area > frontier[best].area) best = k;
+          int32_t c = frontier[best].node;
+          frontier.erase(frontier.begin() + (ptrdiff_t)best);
+          internal_index[(size_t)c] = next++;
+          push_children(frontier, c);
+        }
+        // the largest of what is left is laid out next
+        std::sort(frontier.begin(), frontier.end(), [](const Cand &x, const Cand &y) { return x.area < y.area; });
+        for (const Cand &c : frontier) roots.push_back(c.node);
+      }
+      for (int i = 0; i < s->n_nodes; i++)  // internal nodes the root does not reach
+        if (!s->nodes[i].is_leaf && internal_index[(size_t)i] < 0) internal_index[(size_t)i] = next++;
+    }
+  }
+  lap("node order");
   // ---- flatten
   auto ref_of_element = [&](int e) -> uint32_t {
     RtElementRef er = s->elements[e];
