@@ -74,9 +74,11 @@ extern "C" {
  *                         for a quad that is not axis-aligned, quad.rs:86), so
  *                         the device skips such children when every box of the
  *                         uploaded scene bounds its contents and follows the
- *                         reference's rule otherwise.  This flag forces the
- *                         reference's rule in all cases (same pixels, more node
- *                         visits). */
+ *                         reference's rule otherwise (for every ray, or, when
+ *                         only a few primitives stick out of their leaf boxes,
+ *                         for the rays that pass the true bounds of one of
+ *                         them).  This flag forces the reference's rule for
+ *                         every ray (same pixels, more node visits). */
 #define RT_FLAG_REFERENCE_VISIT_RULE 8
 
 /* RtImage.memory */

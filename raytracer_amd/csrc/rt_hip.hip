@@ -1754,9 +1754,9 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
   }
 
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
-  // the list is put back into raster order after every round that drops pixels, because the
-  // order of the pixels is the order of the rays in every queue, and neighbouring pixels send
-  // rays through the same nodes.
+  // the list is sorted by key again after every round that drops pixels, because the order of
+  // the pixels is the order of the rays in every queue: consecutive keys are the pixels of one
+  // tile, whose rays pass through the same nodes.
   size_t sort_bytes = 0;
   int sort_bits = 1;
   while (sort_bits < 32 && (1ll << sort_bits) < ((int64_t)rp.n_tiles << (2 * kTileLog))) sort_bits++;
@@ -1852,7 +1852,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       else if ((uint64_t)stopped * 5 > n_active) group = std::max(1, group / 2);
     }
     if (stopped == 0) {
-      // nothing dropped: the list in use is still right, and still in raster order
+      // nothing dropped: the list in use is still right, and still sorted
     } else if (next > 0) {
       HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, active[cur ^ 1], active[cur], (int)next, 0, sort_bits, st));
     }
