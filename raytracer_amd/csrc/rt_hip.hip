@@ -229,6 +229,7 @@ struct ExtendTuning {
   int node_min;  // run the queued leaf tests when fewer lanes than this have node work
   int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
   int claim;     // rays a wave takes from a region's counter at a time
+  int tail;      // shrink the last claims of a region
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
@@ -241,6 +242,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   uint32_t *stack = g_lds + lane;
   uint32_t *leafq = g_lds + (size_t)sc.stack_depth * 64 + lane;
   const uint32_t home = blockIdx.x % kRegions;
+  const uint32_t waves_per_region = gridDim.x / kRegions;
   uint32_t region_try = 0;         // regions tried so far (wave-uniform)
   uint32_t w_next = 0, w_end = 0;  // the wave's claimed range of queue entries (wave-uniform)
   bool dry = false;                // every region is exhausted (wave-uniform)
@@ -263,13 +265,20 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         uint32_t r = (home + region_try) % kRegions;
         uint32_t r_count = counts[r * kCounterStride];
         uint32_t off = r_count;
-        if (*(volatile uint32_t *)&work[r * kCounterStride] < r_count) {
-          if (lane == 0) off = atomicAdd(&work[r * kCounterStride], (uint32_t)tune.claim);
+        uint32_t taken = *(volatile uint32_t *)&work[r * kCounterStride];
+        uint32_t claim = (uint32_t)tune.claim;
+        if (taken < r_count) {
+          // the last claims of a region are smaller: a launch ends when its slowest wave does, and
+          // a wave that starts a full claim when the others run dry keeps the chip waiting
+          uint32_t left = r_count - taken;
+          if (tune.tail == 1 && left < waves_per_region * claim) claim = left < waves_per_region * (claim / 4) ? max(64u, claim / 8) : max(64u, claim / 4);
+          if (tune.tail >= 2) claim = max(64u, min(claim, (left / (waves_per_region * (uint32_t)(tune.tail - 1))) & ~63u));
+          if (lane == 0) off = atomicAdd(&work[r * kCounterStride], claim);
           off = __shfl(off, 0);
         }
         if (off < r_count) {
           w_next = r * q.cap + off;
-          w_end = r * q.cap + min(off + (uint32_t)tune.claim, r_count);
+          w_end = r * q.cap + min(off + claim, r_count);
         } else if (++region_try == kRegions) {
           dry = true;
         }
@@ -348,7 +357,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 0};
+  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 1, 0};
+  if (const char *e = getenv("RT_HIP_TAIL")) t.tail = std::max(0, atoi(e));
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
   if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
@@ -1076,6 +1086,7 @@ RenderParams make_params(const RtConfig *cfg) {
   // rows of the shard are row_stride image rows apart: trade tile height for width accordingly
   rp.tile_hlog = kTileLog;
   for (int s = cfg->row_stride; s > 1 && rp.tile_hlog > 0; s >>= 1) rp.tile_hlog--;
+  if (const char *env = getenv("RT_HIP_TILE_HLOG")) rp.tile_hlog = (uint32_t)std::min<int>(2 * (int)kTileLog, std::max(0, atoi(env)));
   rp.tile_wlog = 2 * kTileLog - rp.tile_hlog;
   rp.tiles_x = ((uint32_t)cfg->img_width + (1u << rp.tile_wlog) - 1u) >> rp.tile_wlog;
   rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + (1u << rp.tile_hlog) - 1u) >> rp.tile_hlog);

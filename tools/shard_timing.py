@@ -36,3 +36,4 @@ for n in (1, 2, 4, 8):
         base = t1 - t0
     print(f"shards {n}: render {1e3*(t1-t0):8.1f} ms (x{n} = {100*base/(n*(t1-t0)):5.1f} % of 1 shard)  extend {st.trace_kernel_ms:7.1f} shade {st.shade_kernel_ms:7.1f} "
           f"other {st.other_kernel_ms:6.1f}  rounds {st.batches}  traced/accepted {st.rays_traced/st.rays:.3f}  copy-out {1e3*(t2-t1):6.1f} ms", flush=True)
+    print("   extend ms by depth x shards:", " ".join(f"{n * x:6.1f}" for x in list(st.trace_ms_by_depth)[:8]), flush=True)
