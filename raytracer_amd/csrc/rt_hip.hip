@@ -1859,7 +1859,12 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     // speculate further ahead while at most 5 % stop, back off when more than 20 % do.
     uint32_t stopped = n_active - next;
     if (b + G < rp.max_batches) {
-      if ((uint64_t)stopped * 20 <= n_active) group = std::min(max_group, std::max(rounds == 0 ? first_jump : 1, group * 2));
+      if ((uint64_t)stopped * 20 <= n_active) {
+        // after a quiet first round: at least first_jump batches, and enough of them to half-fill the
+        // buffers -- a small shard of the image would otherwise spend its first rounds on short launches
+        int jump = rounds == 0 ? (int)std::max<int64_t>(first_jump, cap_paths / 2 / ((int64_t)n_active * S)) : 1;
+        group = std::min(max_group, std::max(jump, group * 2));
+      }
       else if ((uint64_t)stopped * 5 > n_active) group = std::max(1, group / 2);
     }
     if (stopped == 0) {
