@@ -1690,12 +1690,15 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
 
   // Paths per round.  A round traces G consecutive batches of every active pixel at once (the
   // batches after a pixel's stopping batch are speculative and dropped by k_accumulate), which
-  // keeps launches large late in a render; HBM is big enough for >100 M paths in flight.
+  // keeps launches large late in a render and rounds few (every launch ends with a tail in which
+  // the chip waits for its slowest wave); HBM is big enough for 2^29 paths in flight (~125 GB).
   const int64_t bytes_per_path = 2 * (9 * 8 + 8 + 4) + (8 + 4) + (int64_t)sizeof(PathRecord);
-  int64_t max_paths = 1ll << 27;
+  int64_t max_paths = 1ll << 29;
   {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_paths = std::min<int64_t>(max_paths, (int64_t)(free_b / 2) / bytes_per_path);
+    size_t held = 0;  // the arena of earlier renders is reused, so it counts as available
+    for (const ArenaBlock &blk : h->arena) held += blk.size;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_paths = std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2) / bytes_per_path);
   }
   if (const char *env = getenv("RT_HIP_MAX_PATHS")) {
     long long v = atoll(env);
