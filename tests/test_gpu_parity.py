@@ -399,6 +399,26 @@ def test_chunked_rounds_give_the_same_image(monkeypatch):
         assert np.array_equal(a[k], b[k]), k
 
 
+def test_node_storage_order_does_not_change_results(monkeypatch, tmp_scene_dir):
+    """Internal nodes in the reference's preorder or in line-sized blocks: same hits, same image."""
+    from raytracer_amd.integrator import ResidentScene
+    ri = knot_scene(tmp_scene_dir, 20000, 40, 40, 8, 2, 2)
+    o, d = random_rays(150_000, seed=31)
+    cfg = ri.config.copy()
+    results = []
+    for order in ("preorder", "blocks"):
+        monkeypatch.setenv("RT_HIP_NODE_ORDER", order)
+        res = ResidentScene(ri.scene, 0)
+        p, t = res.trace_rays(o, d)
+        out, st = res.render(cfg)
+        results.append((p, t, out["linear"], st.rays))
+        res.close()
+    (p0, t0, l0, r0), (p1, t1, l1, r1) = results
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and np.array_equal(l0, l1) and r0 == r1
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    assert np.array_equal(p1, po) and np.array_equal(t1, to)
+
+
 def test_host_integrator_render_and_png(tmp_path):
     ri = c1(width=32, height=24, batch=8)
     st = ri.render(0)
