@@ -261,6 +261,16 @@ int rt_hip_scene_free(RtSceneHandle *handle);
 int rt_hip_render_resident(RtSceneHandle *handle, const RtConfig *cfg, RtImage *out,
                            RtStats *stats);
 
+/* Progress of the renders on this handle, where the reference advances its
+ * progress bar once per finished row (pb.inc(1), integrator.rs:242).  The
+ * device finishes pixels in rounds of sample batches, not in rows, so the
+ * callback gets the share of the shard's sample batches that are done or no
+ * longer needed (0..1, non-decreasing, 1.0 last), after every round, on the
+ * thread that called rt_hip_render_resident.  It must return quickly: the GPU
+ * idles meanwhile.  fn = NULL removes it. */
+typedef void (*RtProgressFn)(void *user, double fraction_done);
+int rt_hip_set_progress(RtSceneHandle *handle, RtProgressFn fn, void *user);
+
 /* One-shot convenience: upload to device 0, render, free. */
 int rt_hip_render(const RtScene *scene, const RtConfig *cfg, RtImage *out, RtStats *stats);
 

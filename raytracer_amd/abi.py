@@ -140,8 +140,9 @@ class RtStats(C.Structure):
 
 HIP_SYMBOLS = [
     "rt_hip_last_error", "rt_hip_device_count", "rt_hip_scene_upload", "rt_hip_scene_free",
-    "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays",
+    "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays", "rt_hip_set_progress",
 ]
+RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
     "rt_host_last_error", "rt_host_new_from_json", "rt_host_new_from_strings", "rt_host_free", "rt_host_prepare",
     "rt_host_scene", "rt_host_config", "rt_host_bvh_depth", "rt_host_element_bbox", "rt_host_render",
@@ -174,6 +175,7 @@ def hip_lib():
         lib.rt_hip_render.argtypes = [C.POINTER(RtScene), C.POINTER(RtConfig), C.POINTER(RtImage), C.POINTER(RtStats)]
         lib.rt_hip_primary_hits.argtypes = [C.c_void_p, C.POINTER(RtConfig), C.c_void_p, C.c_void_p]
         lib.rt_hip_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_hip_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _hip = lib
     return _hip
 

@@ -979,6 +979,8 @@ struct RtSceneHandle {
   std::vector<ArenaBlock> arena;  // scratch blocks, kept until the scene is freed
   std::vector<hipEvent_t> events;
   size_t events_used = 0;
+  RtProgressFn progress = nullptr;
+  void *progress_user = nullptr;
 };
 
 Scratch::Scratch(RtSceneHandle *handle) : h(handle) {
@@ -1878,6 +1880,11 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     n_active = next;
     b += G;
     rounds++;
+    if (h->progress) {
+      // batches still to come for the pixels still active, over all batches of all pixels
+      double left = (double)n_active * (double)(rp.max_batches - b);
+      h->progress(h->progress_user, n_active == 0 || b >= rp.max_batches ? 1.0 : 1.0 - left / ((double)n_pix * (double)rp.max_batches));
+    }
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
@@ -1919,6 +1926,14 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     }
     stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
+  return RT_OK;
+}
+
+int rt_hip_set_progress(RtSceneHandle *h, RtProgressFn fn, void *user) {
+  g_error.clear();
+  if (!h) return fail(RT_ERR_BAD_ARG, "handle is NULL");
+  h->progress = fn;
+  h->progress_user = fn ? user : nullptr;
   return RT_OK;
 }
 

@@ -63,6 +63,13 @@ class ResidentScene:
         abi.check_hip(abi.hip_lib().rt_hip_render_resident(self._h, C.byref(cfg), C.byref(img), C.byref(stats)))
         return out, stats
 
+    def set_progress(self, fn):
+        """fn(fraction_done) after every round of a render on this scene (the reference's progress
+        bar, integrator.rs:242); None removes it."""
+        self._progress = abi.RtProgressFn(lambda _user, frac: fn(frac)) if fn else None  # keep the thunk alive
+        ptr = C.cast(self._progress, C.c_void_p) if self._progress else None
+        abi.check_hip(abi.hip_lib().rt_hip_set_progress(self._h, ptr, None))
+
     def primary_hits(self, cfg):
         n = cfg.n_rows() * cfg.img_width * cfg.sample_batch_size
         prim = np.empty(n, dtype=np.int32)

@@ -419,6 +419,22 @@ def test_node_storage_order_does_not_change_results(monkeypatch, tmp_scene_dir):
     assert np.array_equal(p1, po) and np.array_equal(t1, to)
 
 
+def test_progress_callback(tmp_scene_dir):
+    """Where the reference ticks its progress bar per row (integrator.rs:242) the device reports per round."""
+    ri = knot_scene(tmp_scene_dir, 2000, 48, 48, 8, 12, 2)
+    res = ri.resident(0)
+    seen = []
+    res.set_progress(seen.append)
+    cfg = ri.config.copy()
+    a, st = res.render(cfg)
+    assert len(seen) == st.batches and seen[-1] == 1.0
+    assert all(0.0 <= x <= 1.0 for x in seen) and seen == sorted(seen)
+    res.set_progress(None)
+    n = len(seen)
+    b, _ = res.render(cfg)
+    assert len(seen) == n and np.array_equal(a["linear"], b["linear"])
+
+
 def test_host_integrator_render_and_png(tmp_path):
     ri = c1(width=32, height=24, batch=8)
     st = ri.render(0)
