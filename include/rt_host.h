@@ -57,6 +57,13 @@ int rt_host_element_bbox(RtHostIntegrator *h, int element, double *min3, double 
 /* integrator.rs:161-249 with the Rayon loop replaced by rt_hip_render on
  * `device`.  Fills the integrator's `pixels` and `sample_pixels`. */
 int rt_host_render(RtHostIntegrator *h, int device, RtStats *stats);
+/* The same render on several GPUs of this process: entry r of `devices` gets
+ * the rows r, r+n, r+2n, ... (one scene copy and one host thread per entry;
+ * the reference's rows are independent tasks, integrator.rs:226-243), and the
+ * rows are interleaved back into `pixels` / `sample_pixels`.  The image equals
+ * rt_host_render's bit for bit.  Stats: counts are summed, durations are those
+ * of the slowest shard. */
+int rt_host_render_devices(RtHostIntegrator *h, const int *devices, int n_devices, RtStats *stats);
 const double *rt_host_pixels(RtHostIntegrator *h);        /* width*height*3 */
 const double *rt_host_sample_pixels(RtHostIntegrator *h); /* width*height*3 */
 /* Overwrite the pixel buffers (e.g. with tiles gathered from several GPUs). */

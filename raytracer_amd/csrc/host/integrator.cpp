@@ -2,6 +2,7 @@
 // operator surface (/root/reference/src/render/integrator.rs:38-249):
 // new_from_json -> render -> save_to_png, with the Rayon row loop
 // (integrator.rs:226-243) replaced by one call into rt_hip.h.
+#include <algorithm>
 #include <cstdlib>
 #include <chrono>
 #include <zlib.h>
@@ -13,6 +14,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/rt_host.h"
@@ -32,6 +34,9 @@ class RenderIntegrator {
   bool prepared = false;
   RtSceneHandle *resident = nullptr;
   int resident_device = -1;
+  // one copy of the scene per entry of the device list of render_devices()
+  std::vector<RtSceneHandle *> shard_scenes;
+  std::vector<int> shard_devices;
 
   // integrator.rs:39-61
   RenderIntegrator(Json scene_, Config config_, std::string base_dir_)
@@ -57,6 +62,8 @@ class RenderIntegrator {
 
   ~RenderIntegrator() {
     if (resident) rt_hip_scene_free(resident);
+    for (RtSceneHandle *s : shard_scenes)
+      if (s) rt_hip_scene_free(s);
   }
 
   // integrator.rs:163-192
@@ -120,6 +127,78 @@ class RenderIntegrator {
     img.sample_pixels = sample_pixels.data();
     img.memory = RT_MEM_HOST;
     if (rt_hip_render_resident(resident, &cfg, &img, stats) != RT_OK) throw std::runtime_error(rt_hip_last_error());
+  }
+
+  // The same render split over several GPUs of this process: entry r of `devices` renders the rows
+  // r, r+n, r+2n, ... of the image (pixels are independent given the scene, integrator.rs:226-243, and
+  // interleaving evens out the cost of adaptive sampling) on a thread of its own; the rows are
+  // interleaved back into `pixels` / `sample_pixels` on the host.  The image is the one render() makes.
+  void render_devices(const int *devices, int n, RtStats *stats) {
+    prepare();
+    if (n <= 0 || !devices) throw std::runtime_error("empty device list");
+    const int H = pod_config.img_height, W = pod_config.img_width;
+    if (n > H) n = H;
+    std::vector<int> want(devices, devices + n);
+    if (want != shard_devices) {
+      for (RtSceneHandle *s : shard_scenes)
+        if (s) rt_hip_scene_free(s);
+      shard_scenes.assign((size_t)n, nullptr);
+      shard_devices = want;
+    }
+    std::vector<std::string> errors((size_t)n);
+    std::vector<RtStats> part((size_t)n);
+    std::vector<std::vector<double>> px((size_t)n), heat((size_t)n);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int r = 0; r < n; r++) {
+      pool.emplace_back([&, r] {
+        if (!shard_scenes[(size_t)r] && rt_hip_scene_upload(&pod, want[(size_t)r], &shard_scenes[(size_t)r]) != RT_OK) {
+          errors[(size_t)r] = rt_hip_last_error();
+          return;
+        }
+        RtConfig cfg = pod_config;
+        cfg.row_first = r;
+        cfg.row_stride = n;
+        size_t rows = (size_t)((H - r + n - 1) / n);
+        px[(size_t)r].resize(rows * (size_t)W * 3);
+        heat[(size_t)r].resize(rows * (size_t)W * 3);
+        RtImage img{};
+        img.pixels = px[(size_t)r].data();
+        img.sample_pixels = heat[(size_t)r].data();
+        img.memory = RT_MEM_HOST;
+        if (rt_hip_render_resident(shard_scenes[(size_t)r], &cfg, &img, &part[(size_t)r]) != RT_OK) errors[(size_t)r] = rt_hip_last_error();
+      });
+    }
+    for (std::thread &t : pool) t.join();
+    for (int r = 0; r < n; r++)
+      if (!errors[(size_t)r].empty()) throw std::runtime_error("device " + std::to_string(want[(size_t)r]) + ": " + errors[(size_t)r]);
+    const size_t row_bytes = (size_t)W * 3 * sizeof(double);
+    for (int y = 0; y < H; y++) {
+      size_t r = (size_t)(y % n), local = (size_t)(y / n);
+      std::memcpy(pixels.data() + (size_t)y * W * 3, px[r].data() + local * W * 3, row_bytes);
+      std::memcpy(sample_pixels.data() + (size_t)y * W * 3, heat[r].data() + local * W * 3, row_bytes);
+    }
+    if (stats) {
+      *stats = RtStats{};
+      for (const RtStats &p : part) {
+        stats->rays += p.rays;
+        stats->samples += p.samples;
+        stats->rays_traced += p.rays_traced;
+        stats->node_visits += p.node_visits;
+        stats->leaf_tests += p.leaf_tests;
+        stats->box_tests += p.box_tests;
+        stats->wave_node_steps += p.wave_node_steps;
+        stats->wave_leaf_steps += p.wave_leaf_steps;
+        stats->trace_launches += p.trace_launches;
+        for (int k = 0; k < RT_MAX_DEPTH_STATS; k++) stats->rays_by_depth[k] += p.rays_by_depth[k];
+        // device durations: the slowest shard bounds the render
+        stats->trace_kernel_ms = std::max(stats->trace_kernel_ms, p.trace_kernel_ms);
+        stats->shade_kernel_ms = std::max(stats->shade_kernel_ms, p.shade_kernel_ms);
+        stats->other_kernel_ms = std::max(stats->other_kernel_ms, p.other_kernel_ms);
+        stats->batches = std::max(stats->batches, p.batches);
+      }
+      stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
   }
 
   // ----------------------------------------------------------- PNG output
@@ -281,6 +360,13 @@ int rt_host_render(RtHostIntegrator *h, int device, RtStats *stats) {
   return guarded([&] {
     if (!h) throw std::runtime_error("null integrator");
     h->impl->render(device, stats);
+  });
+}
+
+int rt_host_render_devices(RtHostIntegrator *h, const int *devices, int n_devices, RtStats *stats) {
+  return guarded([&] {
+    if (!h) throw std::runtime_error("null integrator");
+    h->impl->render_devices(devices, n_devices, stats);
   });
 }
 

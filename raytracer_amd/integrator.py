@@ -167,6 +167,13 @@ class RenderIntegrator:
         abi.check_host(abi.host_lib().rt_host_render(self._h, int(device), C.byref(stats)))
         return stats
 
+    def render_devices(self, devices):
+        """render() split over several GPUs of this process: rows r::n go to devices[r], one host thread each."""
+        stats = abi.RtStats()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        abi.check_host(abi.host_lib().rt_host_render_devices(self._h, arr, len(devices), C.byref(stats)))
+        return stats
+
     def _buf(self, ptr):
         cfg = self.config
         n = cfg.img_width * cfg.img_height * 3

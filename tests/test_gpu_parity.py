@@ -419,6 +419,19 @@ def test_node_storage_order_does_not_change_results(monkeypatch, tmp_scene_dir):
     assert np.array_equal(p1, po) and np.array_equal(t1, to)
 
 
+def test_render_devices_interleaves_to_the_single_device_image(tmp_scene_dir):
+    """Three row shards rendered by three host threads (three scene copies on the one GPU of the test box)."""
+    ri = knot_scene(tmp_scene_dir, 2000, 40, 37, 8, 6, 2)
+    st1 = ri.render(0)
+    whole, heat = ri.pixels.copy(), ri.sample_pixels.copy()
+    ri.set_pixels(np.zeros_like(whole), np.zeros_like(heat))
+    st3 = ri.render_devices([0, 0, 0])
+    assert np.array_equal(ri.pixels, whole) and np.array_equal(ri.sample_pixels, heat)
+    assert st3.rays == st1.rays and st3.samples == st1.samples
+    with pytest.raises(abi.RtError):
+        ri.render_devices([0, 99])
+
+
 def test_progress_callback(tmp_scene_dir):
     """Where the reference ticks its progress bar per row (integrator.rs:242) the device reports per round."""
     ri = knot_scene(tmp_scene_dir, 2000, 48, 48, 8, 12, 2)
