@@ -1415,12 +1415,13 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   lap("leaf order");
   // Storage order of the internal nodes.  The reference's preorder puts a node next to its left
   // child only; once the node array outgrows the caches every visit is a 128-byte line fetched for
-  // one 32-byte record.  For large trees the records are laid out in blocks that share a line: a
+  // one 32-byte record.  For very large trees (the ordering pass is serial: 0.1 s per 2 M nodes, worth
+  // it only where it saves more) the records are laid out in blocks that share a line: a
   // block starts at a node and takes in, largest box first (the child a ray is likeliest to enter),
   // descendants until the line is full; what is left over starts the next blocks.
   {
     const char *order_env = getenv("RT_HIP_NODE_ORDER");
-    bool blocks = order_env ? !strcmp(order_env, "blocks") : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)8 << 20);
+    bool blocks = order_env ? !strcmp(order_env, "blocks") : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)64 << 20);
     if (blocks && single_position) {
       constexpr int kPerLine = 128 / (int)sizeof(DevNodeQ);
       struct Cand { int32_t node; float area; };
