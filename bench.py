@@ -32,6 +32,21 @@ RAY_STATE_BYTES = 48 + 12  # k_extend reads origin + direction (6 f64), writes t
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")
 
 
+def rust_crate_check():
+    """bindings/rust/rt-hip-sys is written without a Rust toolchain: if this machine has one, type-check it."""
+    import shutil
+    import subprocess
+    cargo = shutil.which("cargo")
+    if not cargo:
+        return {"cargo": None, "checked": False}
+    try:
+        r = subprocess.run([cargo, "check", "--offline", "--manifest-path", os.path.join(ROOT, "bindings", "rust", "rt-hip-sys", "Cargo.toml")],
+                           capture_output=True, text=True, timeout=300)
+        return {"cargo": cargo, "checked": True, "ok": r.returncode == 0, "stderr_tail": r.stderr[-400:]}
+    except Exception as e:  # a broken toolchain must not cost the benchmark line
+        return {"cargo": cargo, "checked": False, "error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +276,7 @@ def main():
                 "max_rank_kernel_ms_per_step": trace_ms_max / args.steps,
             },
             "cpu_baseline": cpu,
+            "rust_sys_crate": rust_crate_check(),
         }
         if cpu:
             line["speedup_vs_cpu_mrays"] = value / cpu["value"]
