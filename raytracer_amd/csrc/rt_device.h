@@ -57,15 +57,14 @@ struct __attribute__((aligned(16))) DevTriangle {
 };
 static_assert(sizeof(DevTriangle) == 80, "triangle record");
 
-// 64-byte record read when a triangle hit is shaded: Triangle::new's unit
-// normal (triangle.rs:58) and the triangle's Material inlined.
-struct __attribute__((aligned(64))) DevTriShade {
-  double normal[3], albedo[3];
-  double param;
-  int32_t kind;
+// 32-byte record read when a triangle hit is shaded: Triangle::new's unit
+// normal (triangle.rs:58) and the index of the triangle's Material.
+struct __attribute__((aligned(32))) DevTriShade {
+  double normal[3];
+  int32_t material;
   int32_t pad;
 };
-static_assert(sizeof(DevTriShade) == 64, "triangle shade record");
+static_assert(sizeof(DevTriShade) == 32, "triangle shade record");
 
 struct DevQuad {
   double q[3], u[3], v[3], normal[3], w[3];

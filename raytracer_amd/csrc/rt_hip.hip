@@ -519,17 +519,15 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       if (ref != kRefNone && !dead_weight) {
         point = o + d * t;  // Ray::at
         uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
-        if (kind == RT_PRIM_TRIANGLE) {  // one 64-byte record: normal + material
-          const double2 *p = reinterpret_cast<const double2 *>(&sc.tri_shade[idx]);
-          double2 a = p[0], b = p[1], c = p[2], e = p[3];
-          normal = D3(a.x, a.y, b.x);
-          albedo = D3(b.y, c.x, c.y);
-          param = e.x;
-          mkind = (int32_t)(__double_as_longlong(e.y) & 0xffffffffll);
-          front_face = dot(d, normal) < 0.0;
-        } else {
+        {
           uint32_t mat;
-          if (kind == RT_PRIM_QUAD) {
+          if (kind == RT_PRIM_TRIANGLE) {  // one 32-byte record: normal + material index
+            const double2 *p = reinterpret_cast<const double2 *>(&sc.tri_shade[idx]);
+            double2 a = p[0], b = p[1];
+            normal = D3(a.x, a.y, b.x);
+            mat = (uint32_t)(__double_as_longlong(b.y) & 0xffffffffll);
+            front_face = dot(d, normal) < 0.0;
+          } else if (kind == RT_PRIM_QUAD) {
             normal = ld3(sc.quads[idx].normal);
             mat = sc.quads[idx].material;
             front_face = dot(d, normal) < 0.0;
@@ -1578,11 +1576,8 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
       d.element = (uint32_t)e;
       d.rank = leaf_rank_of_element[(size_t)e];
       DevTriShade &sh = tri_shade[(size_t)tri_slot[(size_t)er.index]];
-      const RtMaterial &m = s->materials[t.material];
       sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
-      sh.albedo[0] = m.albedo[0]; sh.albedo[1] = m.albedo[1]; sh.albedo[2] = m.albedo[2];
-      sh.param = m.param;
-      sh.kind = m.kind;
+      sh.material = t.material;
       sh.pad = 0;
     } else if (er.kind == RT_PRIM_QUAD) {
       const RtQuad &q = s->quads[er.index];
