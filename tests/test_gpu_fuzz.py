@@ -64,7 +64,9 @@ def _scene(seed):
                             "rotate": {"theta_x": rng.uniform(-1, 1), "theta_y": rng.uniform(-1, 1), "theta_z": rng.uniform(-1, 1)}}})
     rng.shuffle(els)
     split = "SAH" if seed % 2 == 0 else "Mid"
-    return RenderIntegrator.new({"camera": scenes.camera(), "elements": els}, scenes.config(40, 40, 4, 1, 1, split=split)).prepare()
+    cam = scenes.camera(defocus_angle=0.8 if seed % 4 == 1 else 0.0, focus_dist=900.0)  # thin lens on some seeds
+    depth = [8, 1, 3, 12][seed % 4]
+    return RenderIntegrator.new({"camera": cam, "elements": els}, scenes.config(40, 40, 4, 1, 1, split=split, max_depth=depth)).prepare()
 
 
 @pytest.mark.parametrize("seed", range(24))
