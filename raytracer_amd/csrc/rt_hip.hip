@@ -194,7 +194,10 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
     d3 dir = normalized(pixel_sample - origin);
     uint32_t e = region_place(j, share, q.cap);
-    q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+    // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
+    if (!(sc.camera.defocus_angle <= 0.0)) {
+      q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+    }
     q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
     // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
     q.rng[e] = rng;
@@ -230,6 +233,7 @@ struct ExtendTuning {
   int leafq;     // deferred leaves per lane (1..kMaxLeafQueue)
   int claim;     // rays a wave takes from a region's counter at a time
   int tail;      // shrink the last claims of a region
+  int shared_origin;  // the queue holds primary rays of a camera without a lens: origins are not stored
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
@@ -288,7 +292,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         if (j == kNoRay && cand < w_end) {
           j = cand;
           // queue entries are read once: streaming loads leave the L2 to the nodes and triangles
-          ro = D3(__builtin_nontemporal_load(&q.ox[j]), __builtin_nontemporal_load(&q.oy[j]), __builtin_nontemporal_load(&q.oz[j]));
+          if (tune.shared_origin) ro = ld3(sc.camera.camera_center);
+          else ro = D3(__builtin_nontemporal_load(&q.ox[j]), __builtin_nontemporal_load(&q.oy[j]), __builtin_nontemporal_load(&q.oz[j]));
           rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
           if (GRID) fq = make_rayq(sc, ro, rd);
           else f = make_rayf(ro, rd);
@@ -357,7 +362,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 1, 0};
+  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 1, 0, 0};
   if (const char *e = getenv("RT_HIP_TAIL")) t.tail = std::max(0, atoi(e));
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
@@ -373,11 +378,12 @@ static size_t extend_lds_bytes(const DevScene &sc) { return (size_t)(sc.stack_de
 // Which walk a query takes: 0 the order-free one, 1 the reference's visit rule for every ray,
 // 2 both -- the order-free walk for the rays that stay clear of the out-of-box primitives and
 // the reference's rule for the others.
-static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int pass, int64_t n_upper, hipStream_t st, PathQueue q,
-                               const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
+static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int pass, bool shared_origin, int64_t n_upper, hipStream_t st,
+                               PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
   static const ExtendTuning base = extend_tuning();
   ExtendTuning tune = base;
   tune.pass = pass;
+  tune.shared_origin = shared_origin;
   // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
   // a whole number of them per region
   int64_t claims = (n_upper + tune.claim - 1) / tune.claim;
@@ -398,13 +404,14 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
 
 // `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
 // passes, zeroed by the caller; all kCounterStride words apart.
-static void launch_extend(const DevScene &sc, int mode, bool counted, int64_t n_upper, hipStream_t st, PathQueue q,
+// `shared_origin`: the queue holds the primary rays k_generate wrote for a camera without a lens (no origins stored).
+static void launch_extend(const DevScene &sc, int mode, bool counted, bool shared_origin, int64_t n_upper, hipStream_t st, PathQueue q,
                           const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, uint32_t *work2, unsigned long long *visit_counters) {
   if (mode == 2) {
-    launch_extend_pass(sc, false, counted, 1, n_upper, st, q, count_ptr, hits, work, visit_counters);
-    launch_extend_pass(sc, true, counted, 2, n_upper, st, q, count_ptr, hits, work2, visit_counters);
+    launch_extend_pass(sc, false, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    launch_extend_pass(sc, true, counted, 2, shared_origin, n_upper, st, q, count_ptr, hits, work2, visit_counters);
   } else {
-    launch_extend_pass(sc, mode == 1, counted, 0, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    launch_extend_pass(sc, mode == 1, counted, 0, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
   }
 }
 
@@ -513,7 +520,8 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       pid = q.pid[j];
       rng = q.rng[j];
       T = bounce ? D3(q.tx[j], q.ty[j], q.tz[j]) : D3(1.0, 1.0, 1.0);
-      d3 o = D3(q.ox[j], q.oy[j], q.oz[j]);
+      // primary rays of a camera without a lens all start at its centre; k_generate stores no origin then
+      d3 o = (bounce == 0 && sc.camera.defocus_angle <= 0.0) ? ld3(sc.camera.camera_center) : D3(q.ox[j], q.oy[j], q.oz[j]);
       d = D3(q.dx[j], q.dy[j], q.dz[j]);
       bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
       if (ref != kRefNone && !dead_weight) {
@@ -1835,7 +1843,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
         HIP_TRY(mark_begin(0, k));
-        launch_extend(h->dev, walk, counted, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
+        launch_extend(h->dev, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
                       totals + RT_MAX_DEPTH_STATS + 1);
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1));
@@ -1955,7 +1963,7 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   HIP_TRY(sc.alloc(&d_t, (size_t)n));
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
-  launch_extend(h->dev, walk_mode(h, flags), false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  launch_extend(h->dev, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
