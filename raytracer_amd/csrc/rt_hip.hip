@@ -1710,7 +1710,7 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     long long v = atoll(env);
     if (v >= 1) max_paths = v;
   }
-  int max_group = 32;
+  int max_group = 64;
   if (const char *env = getenv("RT_HIP_MAX_GROUP")) max_group = std::max(1, atoi(env));
   max_paths = std::max<int64_t>(max_paths, S);
   max_paths = std::min<int64_t>(max_paths, 0xfffffff0ll / 3);
