@@ -208,6 +208,9 @@ typedef struct RtImage {
   double *sample_pixels; /* n_rows*width*3: heat-map (factor,1-factor,0) (integrator.rs:333-337) */
   double *linear;        /* n_rows*width*3: stats.mean() before clamp/gamma (not in the reference) */
   uint32_t *samples;     /* n_rows*width: actual_samples per pixel (integrator.rs:315) */
+  uint8_t *rgb8;         /* n_rows*width*3: `pixels` as Color::to_rgb makes them for the PNG (color.rs:47-54:
+                            clamp, truncating cast of c*255), converted on the device; optional */
+  uint8_t *sample_rgb8;  /* n_rows*width*3: `sample_pixels` likewise (integrator.rs:119-153); optional */
   int32_t memory;        /* RT_MEM_HOST | RT_MEM_DEVICE */
   int32_t reserved;
 } RtImage;

@@ -113,6 +113,7 @@ class RtConfig(C.Structure):
 class RtImage(C.Structure):
     _fields_ = [
         ("pixels", C.c_void_p), ("sample_pixels", C.c_void_p), ("linear", C.c_void_p), ("samples", C.c_void_p),
+        ("rgb8", C.c_void_p), ("sample_rgb8", C.c_void_p),
         ("memory", C.c_int32), ("reserved", C.c_int32),
     ]
 

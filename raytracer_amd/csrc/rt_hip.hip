@@ -658,7 +658,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
 struct PixelOutputs {
   double *pixels, *sample_pixels, *linear;
   uint32_t *samples;
+  uint8_t *rgb8, *sample_rgb8;
 };
+// Color::to_rgb, color.rs:47-54: clamp to [0,1], then a truncating cast of c * 255
+__device__ __forceinline__ uint8_t to_rgb8(double c) { return (uint8_t)(fmax(fmin(c, 1.0), 0.0) * 255.0); }
 constexpr int kAccChunk = 4;  // batches k_accumulate evaluates together
 
 // One lane per active pixel.  Processes the G batches of the round in order,
@@ -846,16 +849,29 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
       if (done) {
         // integrator.rs:331: mean.clamp().linear_to_gamma(gamma)
         double inv_g = 1.0 / rp.gamma;
-        out.pixels[3 * (size_t)p + 0] = pow(fmax(fmin(mr, 1.0), 0.0), inv_g);
-        out.pixels[3 * (size_t)p + 1] = pow(fmax(fmin(mg, 1.0), 0.0), inv_g);
-        out.pixels[3 * (size_t)p + 2] = pow(fmax(fmin(mb, 1.0), 0.0), inv_g);
+        double pr = pow(fmax(fmin(mr, 1.0), 0.0), inv_g), pg = pow(fmax(fmin(mg, 1.0), 0.0), inv_g), pb = pow(fmax(fmin(mb, 1.0), 0.0), inv_g);
+        out.pixels[3 * (size_t)p + 0] = pr;
+        out.pixels[3 * (size_t)p + 1] = pg;
+        out.pixels[3 * (size_t)p + 2] = pb;
+        if (out.rgb8) {
+          out.rgb8[3 * (size_t)p + 0] = to_rgb8(pr);
+          out.rgb8[3 * (size_t)p + 1] = to_rgb8(pg);
+          out.rgb8[3 * (size_t)p + 2] = to_rgb8(pb);
+        }
         uint64_t actual = (uint64_t)nb * (uint64_t)rp.S;
-        if (out.sample_pixels) {  // integrator.rs:333-337 (usize arithmetic wraps)
+        if (out.sample_pixels || out.sample_rgb8) {  // integrator.rs:333-337 (usize arithmetic wraps)
           uint64_t num = actual - (uint64_t)rp.min_batches * (uint64_t)rp.S;
           double factor = (double)num / (double)((uint64_t)rp.S * (uint64_t)rp.max_batches);
-          out.sample_pixels[3 * (size_t)p + 0] = factor * 1.0;
-          out.sample_pixels[3 * (size_t)p + 1] = (1.0 - factor) * 1.0;
-          out.sample_pixels[3 * (size_t)p + 2] = 0.0;
+          if (out.sample_pixels) {
+            out.sample_pixels[3 * (size_t)p + 0] = factor * 1.0;
+            out.sample_pixels[3 * (size_t)p + 1] = (1.0 - factor) * 1.0;
+            out.sample_pixels[3 * (size_t)p + 2] = 0.0;
+          }
+          if (out.sample_rgb8) {
+            out.sample_rgb8[3 * (size_t)p + 0] = to_rgb8(factor * 1.0);
+            out.sample_rgb8[3 * (size_t)p + 1] = to_rgb8((1.0 - factor) * 1.0);
+            out.sample_rgb8[3 * (size_t)p + 2] = 0;
+          }
         }
         if (out.linear) {
           out.linear[3 * (size_t)p + 0] = mr;
@@ -1766,11 +1782,15 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     po.sample_pixels = out->sample_pixels;
     po.linear = out->linear;
     po.samples = out->samples;
+    po.rgb8 = out->rgb8;
+    po.sample_rgb8 = out->sample_rgb8;
   } else {
     HIP_TRY(sc.alloc(&po.pixels, 3 * (size_t)n_pix));
     if (out->sample_pixels) HIP_TRY(sc.alloc(&po.sample_pixels, 3 * (size_t)n_pix));
     if (out->linear) HIP_TRY(sc.alloc(&po.linear, 3 * (size_t)n_pix));
     if (out->samples) HIP_TRY(sc.alloc(&po.samples, (size_t)n_pix));
+    if (out->rgb8) HIP_TRY(sc.alloc(&po.rgb8, 3 * (size_t)n_pix));
+    if (out->sample_rgb8) HIP_TRY(sc.alloc(&po.sample_rgb8, 3 * (size_t)n_pix));
   }
 
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
@@ -1898,6 +1918,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
     if (out->sample_pixels) HIP_TRY(hipMemcpy(out->sample_pixels, po.sample_pixels, 3 * (size_t)n_pix * sizeof(double), hipMemcpyDeviceToHost));
     if (out->linear) HIP_TRY(hipMemcpy(out->linear, po.linear, 3 * (size_t)n_pix * sizeof(double), hipMemcpyDeviceToHost));
     if (out->samples) HIP_TRY(hipMemcpy(out->samples, po.samples, (size_t)n_pix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (out->rgb8) HIP_TRY(hipMemcpy(out->rgb8, po.rgb8, 3 * (size_t)n_pix, hipMemcpyDeviceToHost));
+    if (out->sample_rgb8) HIP_TRY(hipMemcpy(out->sample_rgb8, po.sample_rgb8, 3 * (size_t)n_pix, hipMemcpyDeviceToHost));
   }
   if (stats) {
     memset(stats, 0, sizeof *stats);

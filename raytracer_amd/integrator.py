@@ -32,7 +32,7 @@ class ResidentScene:
         except Exception:
             pass
 
-    def render(self, cfg, want_linear=True, want_samples=True, device_out=None):
+    def render(self, cfg, want_linear=True, want_samples=True, device_out=None, want_rgb8=False):
         """Render the row shard named by cfg.  Returns (dict of numpy arrays, RtStats).
 
         With `device_out` (a dict of torch CUDA tensors named pixels / sample_pixels /
@@ -43,7 +43,7 @@ class ResidentScene:
         stats = abi.RtStats()
         if device_out is not None:
             img.memory = abi.RT_MEM_DEVICE
-            for name in ("pixels", "sample_pixels", "linear", "samples"):
+            for name in ("pixels", "sample_pixels", "linear", "samples", "rgb8", "sample_rgb8"):
                 t = device_out.get(name)
                 if t is not None:
                     setattr(img, name, t.data_ptr())
@@ -57,6 +57,9 @@ class ResidentScene:
             out["linear"] = np.empty((n_rows, w, 3), dtype=np.float64)
         if want_samples:
             out["samples"] = np.empty((n_rows, w), dtype=np.uint32)
+        if want_rgb8:  # what save_to_png writes (color.rs:47-54), converted on the device
+            out["rgb8"] = np.empty((n_rows, w, 3), dtype=np.uint8)
+            out["sample_rgb8"] = np.empty((n_rows, w, 3), dtype=np.uint8)
         img.memory = abi.RT_MEM_HOST
         for name, arr in out.items():
             setattr(img, name, arr.ctypes.data)

@@ -432,6 +432,15 @@ def test_render_devices_interleaves_to_the_single_device_image(tmp_scene_dir):
         ri.render_devices([0, 99])
 
 
+def test_rgb8_outputs_are_to_rgb_of_the_pixels(tmp_scene_dir):
+    """Color::to_rgb (color.rs:47-54) on the device: clamp, then a truncating cast of c * 255."""
+    ri = knot_scene(tmp_scene_dir, 2000, 48, 40, 8, 6, 1)
+    out, _ = ri.resident(0).render(ri.config.copy(), want_rgb8=True)
+    assert np.array_equal(out["rgb8"], (np.clip(out["pixels"], 0.0, 1.0) * 255.0).astype(np.uint8))
+    assert np.array_equal(out["sample_rgb8"], (np.clip(out["sample_pixels"], 0.0, 1.0) * 255.0).astype(np.uint8))
+    assert out["rgb8"].max() > 100 and len(np.unique(out["sample_rgb8"][..., 0])) > 1
+
+
 def test_progress_callback(tmp_scene_dir):
     """Where the reference ticks its progress bar per row (integrator.rs:242) the device reports per round."""
     ri = knot_scene(tmp_scene_dir, 2000, 48, 48, 8, 12, 2)
