@@ -432,6 +432,27 @@ def test_render_devices_interleaves_to_the_single_device_image(tmp_scene_dir):
         ri.render_devices([0, 99])
 
 
+def test_round_size_does_not_change_the_image(monkeypatch, tmp_scene_dir):
+    """Batches are traced in rounds of several at once, speculatively past a pixel's stopping batch; however the
+    rounds are cut, every pixel must end with the batches the reference's sequential loop would have used."""
+    ri = knot_scene(tmp_scene_dir, 2000, 40, 40, 32, 40, 1)
+    cfg = ri.config.copy()
+    res = ri.resident(0)
+    outs = []
+    for group, first in (("1", "1"), ("5", "3"), ("64", "8"), ("64", "64")):
+        monkeypatch.setenv("RT_HIP_MAX_GROUP", group)
+        monkeypatch.setenv("RT_HIP_FIRST_GROUP", first)
+        out, st = res.render(cfg)
+        outs.append((out, int(st.rays), int(st.samples), int(st.batches)))
+    assert len({o[3] for o in outs}) > 1  # the rounds really differed
+    stopped_early = (outs[0][0]["samples"] < 32 * 40).mean()
+    assert 0.03 < stopped_early < 0.97, stopped_early
+    for out, rays, samples, _ in outs[1:]:
+        for k in out:
+            assert np.array_equal(out[k], outs[0][0][k]), k
+        assert rays == outs[0][1] and samples == outs[0][2]
+
+
 def test_rgb8_outputs_are_to_rgb_of_the_pixels(tmp_scene_dir):
     """Color::to_rgb (color.rs:47-54) on the device: clamp, then a truncating cast of c * 255."""
     ri = knot_scene(tmp_scene_dir, 2000, 48, 40, 8, 6, 1)
