@@ -225,6 +225,9 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
 extern __shared__ uint32_t g_lds[];
 
 constexpr uint32_t kClaim = 512;
+#ifndef RT_EXTRA_STEPS
+#define RT_EXTRA_STEPS 1
+#endif
 constexpr uint32_t kNoRay = 0xffffffffu;
 
 struct ExtendTuning {
@@ -327,6 +330,16 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         else trav_node<QUIRK>(sc, f, tv, stack, stride);
       }
       if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
+#pragma unroll
+      for (int extra = 0; extra < (QUIRK ? 0 : RT_EXTRA_STEPS); extra++) {  // more steps before the wave votes again
+        if (COUNT) wn++;
+        if (!(tv.cur & kRefLeaf)) {
+          if (COUNT) nn++;
+          if (GRID) trav_node_q(sc, fq, tv, stack, stride);
+          else trav_node<QUIRK>(sc, f, tv, stack, stride);
+        }
+        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
+      }
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
     // ------------------------------------------------------------ leaf phase
     pending = __ballot(tv.qn > 0) != 0;
@@ -362,7 +375,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
 }
 
 static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 16, kMaxLeafQueue, (int)kClaim, 1, 0, 0};
+  ExtendTuning t{40, 20, kMaxLeafQueue, (int)kClaim, 1, 0, 0};
   if (const char *e = getenv("RT_HIP_TAIL")) t.tail = std::max(0, atoi(e));
   if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
   if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
