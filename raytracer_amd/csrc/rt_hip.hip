@@ -515,8 +515,14 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t in0 = region * q.cap, out0 = region * out.cap;
   uint32_t *out_counter = out_count + region * kCounterStride;
-  for (uint32_t jj = (blockIdx.x / kRegions) * blockDim.x + threadIdx.x; jj < n_round; jj += stride) {
+  // the hit reference of the NEXT trip is fetched one trip ahead: the shading record it names is
+  // then requested together with the path state instead of one memory latency after it
+  const uint32_t jj0 = (blockIdx.x / kRegions) * blockDim.x + threadIdx.x;
+  uint32_t ref_ahead = jj0 < n ? hits.ref[in0 + jj0] : kRefNone;
+  for (uint32_t jj = jj0; jj < n_round; jj += stride) {
     const uint32_t j = in0 + jj;
+    const uint32_t ref_now = ref_ahead;
+    ref_ahead = (jj + stride < n) ? hits.ref[j + stride] : kRefNone;
     // ---- phase A: load, classify, decide whether the path goes on
     bool alive = false;
     int32_t mkind = -1;
@@ -528,7 +534,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
     uint32_t pid = 0;
     if (jj < n) {
       // every load of the path state is issued before the first use
-      uint32_t ref = hits.ref[j];
+      uint32_t ref = ref_now;
       double t = hits.t[j];
       pid = q.pid[j];
       rng = q.rng[j];
