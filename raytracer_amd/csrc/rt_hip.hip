@@ -1876,7 +1876,8 @@ int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, 
       int g = grid_for(np, block, max_blocks);
       // k_shade: a whole number of workgroups per region, and many more of them than fit the
       // chip at once -- short workgroups even out the uneven cost of the material branches
-      int g_shade = (int)std::min<int64_t>(256 * 64, (np / block / kRegions + 1) * kRegions);
+      static const int shade_blocks = getenv("RT_HIP_SHADE_BLOCKS") ? std::max((int)kRegions, atoi(getenv("RT_HIP_SHADE_BLOCKS")) / (int)kRegions * (int)kRegions) : 256 * 64;
+      int g_shade = (int)std::min<int64_t>(shade_blocks, (np / block / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
       hipLaunchKernelGGL(k_generate, dim3(g), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
       HIP_TRY(mark_end());
