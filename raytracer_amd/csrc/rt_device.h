@@ -96,6 +96,7 @@ struct DevScene {
   const DevMaterial *materials;
   const uint32_t *attractors;  // leaf refs (kind + index)
   int32_t n_attractors;
+  int32_t n_materials;
   uint32_t root;        // ref of nodes[0] of the reference array
   int32_t stack_depth;  // LDS stack entries per lane
   int32_t quirk;        // 1 when the walk must follow the reference's visit rule step by step: some child box

@@ -506,6 +506,17 @@ struct PathResults {
 
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
                                                 uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
+  // a small material table is staged in LDS: the lookup sits on the dependent chain
+  // hit reference -> shading record -> material -> "does the path go on?"
+  constexpr int kLdsMaterials = 256;
+  __shared__ DevMaterial lds_materials[kLdsMaterials];
+  const bool staged = sc.n_materials <= kLdsMaterials;
+  if (staged) {
+    const uint32_t words = (uint32_t)sc.n_materials * (uint32_t)(sizeof(DevMaterial) / 4);
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x)
+      reinterpret_cast<uint32_t *>(lds_materials)[w] = reinterpret_cast<const uint32_t *>(sc.materials)[w];
+    __syncthreads();
+  }
   // workgroup b serves region b % kRegions (gridDim is a multiple of kRegions)
   const uint32_t region = blockIdx.x % kRegions;
   const uint32_t n = count_ptr[region * kCounterStride];
@@ -565,10 +576,17 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
             normal = front_face ? outward : neg(outward);
             mat = sp.material;
           }
-          const DevMaterial &m = sc.materials[mat];
-          albedo = ld3(m.albedo);
-          param = m.param;
-          mkind = m.kind;
+          if (staged) {
+            const DevMaterial &m = lds_materials[mat];
+            albedo = ld3(m.albedo);
+            param = m.param;
+            mkind = m.kind;
+          } else {
+            const DevMaterial &m = sc.materials[mat];
+            albedo = ld3(m.albedo);
+            param = m.param;
+            mkind = m.kind;
+          }
         }
         // every material but the dielectric (white attenuation) scales the throughput by its
         // albedo first; the product is commutative, so one multiplication serves them all
@@ -1693,6 +1711,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
     return rc;
   }
   h->dev.n_attractors = s->n_attractors;
+  h->dev.n_materials = s->n_materials;
   h->dev.root = ref_of_node(0);
   h->dev.stack_depth = std::max(max_depth, 1);
   h->dev.quirk = boxes_bound_contents ? 0 : 1;
