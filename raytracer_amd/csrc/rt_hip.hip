@@ -170,9 +170,10 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
   if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
   uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
   for (int64_t j = (int64_t)lb * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    int32_t i = (int32_t)(j % rp.S);
-    int64_t sg = j / rp.S;
-    int32_t g = (int32_t)(sg % G), slot = (int32_t)(sg / G);
+    // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit divisions, not 64-bit ones
+    uint32_t j32 = (uint32_t)j, sg = j32 / (uint32_t)rp.S;
+    int32_t i = (int32_t)(j32 - sg * (uint32_t)rp.S);
+    int32_t slot = (int32_t)(sg / (uint32_t)G), g = (int32_t)(sg - (uint32_t)slot * (uint32_t)G);
     uint32_t p = pixel_of_key(rp, active[slot]);
     int32_t x = (int32_t)(p % (uint32_t)rp.width);
     int32_t y = rp.row_first + (int32_t)(p / (uint32_t)rp.width) * rp.row_stride;
