@@ -1224,18 +1224,42 @@ static int upload_threads() {
   return hw == 0 ? 1 : (int)std::min(hw, 64u);
 }
 template <typename F>
-static void parallel_for(size_t n, F &&fn) {  // fn(begin, end) over [0, n), exceptions not expected
+static void parallel_for(size_t n, F &&fn) {  // fn(begin, end) over [0, n); a worker's exception is rethrown on the caller
   int threads = upload_threads();
   if (threads <= 1 || n < 65536) {
     fn((size_t)0, n);
     return;
   }
   std::vector<std::thread> pool;
-  for (int c = 0; c < threads; c++) pool.emplace_back([&, c] { fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads); });
+  std::vector<std::exception_ptr> failures((size_t)threads);
+  for (int c = 0; c < threads; c++)
+    pool.emplace_back([&, c] {
+      try {
+        fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
+      } catch (...) {
+        failures[(size_t)c] = std::current_exception();
+      }
+    });
   for (auto &t : pool) t.join();
+  for (auto &f : failures)
+    if (f) std::rethrow_exception(f);
 }
 
-int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
+// No exception may cross the C boundary: every entry point runs its body through this.
+template <typename F>
+static int guarded(F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(RT_ERR_OOM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(RT_ERR_HIP, std::string("unexpected exception: ") + e.what());
+  } catch (...) {
+    return fail(RT_ERR_HIP, "unexpected exception");
+  }
+}
+
+static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) {
   g_error.clear();
   if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
   *out = nullptr;
@@ -1272,6 +1296,9 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   for (int i = 0; i < s->n_attractors; i++) {
     int e = s->attractors[i];
     if (e < 0 || e >= s->n_elements) return fail(RT_ERR_BAD_ARG, "attractor index out of range");
+    // only spheres and quads can be attractors (elements/mod.rs:68-75); the sampling code has no triangle branch
+    if (s->elements[e].kind != RT_PRIM_QUAD && s->elements[e].kind != RT_PRIM_SPHERE)
+      return fail(RT_ERR_BAD_ARG, "attractor " + std::to_string(i) + " is not a quad or a sphere");
   }
   // nodes: children must lie after their parent (the reference's vector is
   // preorder), which also rules out cycles; leaves must name a valid element.
@@ -1687,6 +1714,12 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   HIP_TRY(hipSetDevice(device));
   RtSceneHandle *h = new (std::nothrow) RtSceneHandle;
   if (!h) return fail(RT_ERR_OOM, "out of host memory");
+  struct FreeOnUnwind {  // an exception below (host allocation) must not leak the device copies made so far
+    RtSceneHandle *h;
+    ~FreeOnUnwind() {
+      if (h) rt_hip_scene_free(h);
+    }
+  } unwind{h};
   h->device = device;
   h->n_elements = s->n_elements;
   h->bvh_depth = max_depth;
@@ -1705,12 +1738,7 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   step(dev_upload(h, &h->dev.materials, mats));
   step(dev_upload(h, &h->dev.attractors, attractors));
   if (rc == RT_OK && hipStreamCreate(&h->stream) != hipSuccess) rc = fail(RT_ERR_HIP, "hipStreamCreate failed");
-  if (rc != RT_OK) {
-    std::string keep = g_error;
-    rt_hip_scene_free(h);
-    g_error = keep;
-    return rc;
-  }
+  if (rc != RT_OK) return rc;  // `unwind` frees the handle; the message stays
   h->dev.n_attractors = s->n_attractors;
   h->dev.n_materials = s->n_materials;
   h->dev.root = ref_of_node(0);
@@ -1720,21 +1748,17 @@ int rt_hip_scene_upload(const RtScene *s, int device, RtSceneHandle **out) {
   h->dev.n_danger = 0;
   if (fast_walk_exists && !boxes_bound_contents) {
     rc = dev_upload(h, &h->dev.danger, danger);
-    if (rc != RT_OK) {
-      std::string keep = g_error;
-      rt_hip_scene_free(h);
-      g_error = keep;
-      return rc;
-    }
+    if (rc != RT_OK) return rc;
     h->dev.n_danger = (int32_t)(danger.size() / 6);
   }
   h->dev.camera = s->camera;
   lap("device copies");
+  unwind.h = nullptr;
   *out = h;
   return RT_OK;
 }
 
-int rt_hip_render_resident(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, RtStats *stats) {
+static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *out, RtStats *stats) {
   g_error.clear();
   if (!h || !out || !out->pixels) return fail(RT_ERR_BAD_ARG, "handle, out or out->pixels is NULL");
   int rc = check_config(cfg);
@@ -2003,17 +2027,6 @@ int rt_hip_set_progress(RtSceneHandle *h, RtProgressFn fn, void *user) {
   return RT_OK;
 }
 
-int rt_hip_render(const RtScene *scene, const RtConfig *cfg, RtImage *out, RtStats *stats) {
-  RtSceneHandle *h = nullptr;
-  int rc = rt_hip_scene_upload(scene, 0, &h);
-  if (rc != RT_OK) return rc;
-  rc = rt_hip_render_resident(h, cfg, out, stats);
-  std::string keep = g_error;
-  rt_hip_scene_free(h);
-  g_error = keep;
-  return rc;
-}
-
 static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, uint32_t *d_counts, int32_t flags, int32_t *prim_id, double *t) {
   const size_t entries = (size_t)q.cap * kRegions;
   HitBuffer hits;
@@ -2048,7 +2061,7 @@ static int alloc_ray_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue *
   return RT_OK;
 }
 
-int rt_hip_primary_hits(RtSceneHandle *h, const RtConfig *cfg, int32_t *prim_id, double *t) {
+static int primary_hits_impl(RtSceneHandle *h, const RtConfig *cfg, int32_t *prim_id, double *t) {
   g_error.clear();
   if (!h || !prim_id || !t) return fail(RT_ERR_BAD_ARG, "NULL argument");
   int rc = check_config(cfg);
@@ -2065,7 +2078,7 @@ int rt_hip_primary_hits(RtSceneHandle *h, const RtConfig *cfg, int32_t *prim_id,
   return trace_queue(h, sc, n, q, d_count, cfg->flags, prim_id, t);
 }
 
-int rt_hip_trace_rays(RtSceneHandle *h, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
+static int trace_rays_impl(RtSceneHandle *h, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
   g_error.clear();
   if (!h || n < 0 || (n > 0 && (!origins || !directions || !prim_id || !t))) return fail(RT_ERR_BAD_ARG, "NULL argument or negative count");
   if (n == 0) return RT_OK;
@@ -2082,4 +2095,30 @@ int rt_hip_trace_rays(RtSceneHandle *h, int64_t n, const double *origins, const 
   if (rc != RT_OK) return rc;
   hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_o, d_d, q, d_count);
   return trace_queue(h, sc, n, q, d_count, 0, prim_id, t);
+}
+
+// ------------------------------------------------------- the C entry points
+int rt_hip_scene_upload(const RtScene *scene, int device, RtSceneHandle **out) {
+  return guarded([&] { return scene_upload_impl(scene, device, out); });
+}
+int rt_hip_render_resident(RtSceneHandle *handle, const RtConfig *cfg, RtImage *out, RtStats *stats) {
+  return guarded([&] { return render_resident_impl(handle, cfg, out, stats); });
+}
+int rt_hip_render(const RtScene *scene, const RtConfig *cfg, RtImage *out, RtStats *stats) {
+  return guarded([&] {
+    RtSceneHandle *h = nullptr;
+    int rc = scene_upload_impl(scene, 0, &h);
+    if (rc != RT_OK) return rc;
+    rc = render_resident_impl(h, cfg, out, stats);
+    std::string keep = g_error;
+    rt_hip_scene_free(h);
+    g_error = keep;
+    return rc;
+  });
+}
+int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *prim_id, double *t) {
+  return guarded([&] { return primary_hits_impl(handle, cfg, prim_id, t); });
+}
+int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
+  return guarded([&] { return trace_rays_impl(handle, n, origins, directions, prim_id, t); });
 }

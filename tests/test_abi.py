@@ -103,6 +103,11 @@ def test_scene_validation_rejects_bad_indices_before_any_kernel():
     att = (C.c_int32 * 1)(-5)
     s = copy(); s.attractors = att
     assert upload(s) == abi.RT_ERR_BAD_ARG
+    # only spheres and quads can be attractors (elements/mod.rs:68-75): a triangle element is refused
+    tri_element = next(i for i in range(sc.n_elements) if sc.elements[i].kind == abi.RT_PRIM_TRIANGLE)
+    att = (C.c_int32 * 1)(tri_element)
+    s = copy(); s.attractors = att
+    assert upload(s) == abi.RT_ERR_BAD_ARG and b"not a quad or a sphere" in lib.rt_hip_last_error()
 
 
 def test_the_package_has_no_cpu_rendering_path():
