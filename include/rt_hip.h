@@ -290,6 +290,21 @@ int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *pri
 int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins,
                       const double *directions, int32_t *prim_id, double *t);
 
+/* The queries of rt_hip_trace_rays for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  The call makes
+ * no hipMalloc / hipFree and uses no allocating library routine: the ray
+ * queue, hit buffer and counters live in a fixed array inside the library's
+ * code object (about 7.5 MiB per GPU, held until the process ends).
+ *   - d_origins, d_directions (3*n doubles each), d_prim_id, d_t (n each) are
+ *     DEVICE pointers on the handle's device; results are complete on return.
+ *   - n <= RT_NOALLOC_MAX_RAYS, otherwise RT_ERR_UNSUPPORTED (split the batch).
+ *   - All calls on one GPU share that GPU's array: calls that overlap on one
+ *     GPU (two threads, two handles) race; serialise them. */
+#define RT_NOALLOC_MAX_RAYS 131072
+int rt_hip_trace_rays_noalloc(RtSceneHandle *handle, int64_t n, const double *d_origins,
+                              const double *d_directions, int32_t *d_prim_id, double *d_t);
+
 #ifdef __cplusplus
 }
 #endif

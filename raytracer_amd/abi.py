@@ -23,6 +23,7 @@ RT_RNG_REF, RT_RNG_CTR = 0, 1
 RT_FLAG_TIME_KERNELS, RT_FLAG_COUNT_VISITS, RT_FLAG_EARLY_TERMINATE, RT_FLAG_REFERENCE_VISIT_RULE = 1, 2, 4, 8
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 RT_MAX_DEPTH_STATS = 16
+RT_NOALLOC_MAX_RAYS = 131072
 
 
 class RtVec3(C.Structure):
@@ -142,6 +143,7 @@ class RtStats(C.Structure):
 HIP_SYMBOLS = [
     "rt_hip_last_error", "rt_hip_device_count", "rt_hip_scene_upload", "rt_hip_scene_free",
     "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays", "rt_hip_set_progress",
+    "rt_hip_trace_rays_noalloc",
 ]
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
@@ -177,6 +179,7 @@ def hip_lib():
         lib.rt_hip_primary_hits.argtypes = [C.c_void_p, C.POINTER(RtConfig), C.c_void_p, C.c_void_p]
         lib.rt_hip_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_hip_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_hip_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip = lib
     return _hip
 

@@ -1041,6 +1041,7 @@ struct RtSceneHandle {
   size_t events_used = 0;
   RtProgressFn progress = nullptr;
   void *progress_user = nullptr;
+  void *noalloc_scratch = nullptr;  // this device's address of the file-scope scratch array (rt_hip_trace_rays_noalloc)
 };
 
 Scratch::Scratch(RtSceneHandle *handle) : h(handle) {
@@ -1258,6 +1259,8 @@ static int guarded(F &&body) {
     return fail(RT_ERR_HIP, "unexpected exception");
   }
 }
+
+static int noalloc_scratch_of(int device, void **out);  // per-device address of the scratch array of rt_hip_trace_rays_noalloc
 
 static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) {
   g_error.clear();
@@ -1738,6 +1741,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   step(dev_upload(h, &h->dev.materials, mats));
   step(dev_upload(h, &h->dev.attractors, attractors));
   if (rc == RT_OK && hipStreamCreate(&h->stream) != hipSuccess) rc = fail(RT_ERR_HIP, "hipStreamCreate failed");
+  if (rc == RT_OK) rc = noalloc_scratch_of(device, &h->noalloc_scratch);
   if (rc != RT_OK) return rc;  // `unwind` frees the handle; the message stays
   h->dev.n_attractors = s->n_attractors;
   h->dev.n_materials = s->n_materials;
@@ -2097,6 +2101,74 @@ static int trace_rays_impl(RtSceneHandle *h, int64_t n, const double *origins, c
   return trace_queue(h, sc, n, q, d_count, 0, prim_id, t);
 }
 
+// ------------------------------------------- closest-hit queries that allocate nothing
+// rt_hip_trace_rays_noalloc: the queries of rt_hip_trace_rays for callers that cannot allocate
+// device memory.  Everything the kernels need beyond the caller's inputs and outputs -- the SoA
+// ray queue, the hit buffer, the region counts and claim counters -- lives in this file-scope
+// array of the code object.  Every GPU the library runs on holds its own copy at its own address
+// until the process ends; host code never passes the array's name to a kernel or a memset, only
+// the per-device address hipGetSymbolAddress returned for it (noalloc_scratch_of).
+constexpr int64_t kNoAllocMaxRays = 1 << 17;
+static_assert(kNoAllocMaxRays == RT_NOALLOC_MAX_RAYS, "the header states the limit");
+constexpr size_t kNoAllocRegionCap = (size_t)(((kNoAllocMaxRays + kRegions - 1) / kRegions + 63) / 64 * 64);
+constexpr size_t kNoAllocEntries = kNoAllocRegionCap * kRegions;
+constexpr size_t kNoAllocCounterWords = 3 * (size_t)kRegions * kCounterStride;  // region counts + two sets of claim counters
+constexpr size_t kNoAllocCounterBytes = (kNoAllocCounterWords * sizeof(uint32_t) + 255) / 256 * 256;
+constexpr size_t kNoAllocBytes = kNoAllocCounterBytes + kNoAllocEntries * (6 * sizeof(double) + sizeof(double) + sizeof(uint32_t));
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_noalloc_mutex;
+static void *g_noalloc_ptr[kMaxDevices];  // device address of `scratch` on each device, once known
+
+// Device address of `scratch` on `device`, which must be the current device.  Looked up once per
+// device (at scene upload: set-up time, where loading the code object may allocate).
+static int noalloc_scratch_of(int device, void **out) {
+  if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_UNSUPPORTED, "device index beyond the table of scratch addresses");
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (!g_noalloc_ptr[device]) {
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+    g_noalloc_ptr[device] = ptr;
+  }
+  *out = g_noalloc_ptr[device];
+  return RT_OK;
+}
+
+static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_origins, const double *d_directions, int32_t *d_prim_id,
+                                   double *d_t) {
+  g_error.clear();
+  if (!h || n < 0 || (n > 0 && (!d_origins || !d_directions || !d_prim_id || !d_t))) return fail(RT_ERR_BAD_ARG, "NULL argument or negative count");
+  if (n > kNoAllocMaxRays)
+    return fail(RT_ERR_UNSUPPORTED, "rt_hip_trace_rays_noalloc takes at most " + std::to_string(kNoAllocMaxRays) + " rays per call, got " +
+                                        std::to_string(n) + ": split the batch or use rt_hip_trace_rays");
+  if (n == 0) return RT_OK;
+  if (!h->noalloc_scratch) return fail(RT_ERR_HIP, "the scene handle has no scratch address");
+  HIP_TRY(hipSetDevice(h->device));
+  // carve the device's copy of the array: counters first, then the queue and the hit buffer
+  unsigned char *base = static_cast<unsigned char *>(h->noalloc_scratch);
+  uint32_t *d_counts = reinterpret_cast<uint32_t *>(base);
+  double *cols = reinterpret_cast<double *>(base + kNoAllocCounterBytes);
+  PathQueue q{};
+  q.cap = (uint32_t)(((n + kRegions - 1) / kRegions + 63) / 64 * 64);  // <= kNoAllocRegionCap
+  const size_t entries = (size_t)q.cap * kRegions;
+  q.ox = cols; q.oy = cols + entries; q.oz = cols + 2 * entries;
+  q.dx = cols + 3 * entries; q.dy = cols + 4 * entries; q.dz = cols + 5 * entries;
+  HitBuffer hits;
+  hits.t = cols + 6 * entries;
+  hits.ref = reinterpret_cast<uint32_t *>(cols + 7 * entries);
+  // the array keeps the last call's contents: the counters must start at zero
+  HIP_TRY(hipMemsetAsync(d_counts, 0, kNoAllocCounterBytes, h->stream));
+  hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_origins, d_directions, q, d_counts);
+  uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
+  launch_extend(h->dev, walk_mode(h, 0), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, n, q.cap, hits, d_prim_id, d_t);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return RT_OK;
+}
+
 // ------------------------------------------------------- the C entry points
 int rt_hip_scene_upload(const RtScene *scene, int device, RtSceneHandle **out) {
   return guarded([&] { return scene_upload_impl(scene, device, out); });
@@ -2121,4 +2193,8 @@ int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *pri
 }
 int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
   return guarded([&] { return trace_rays_impl(handle, n, origins, directions, prim_id, t); });
+}
+int rt_hip_trace_rays_noalloc(RtSceneHandle *handle, int64_t n, const double *d_origins, const double *d_directions, int32_t *d_prim_id,
+                              double *d_t) {
+  return guarded([&] { return trace_rays_noalloc_impl(handle, n, d_origins, d_directions, d_prim_id, d_t); });
 }

@@ -92,6 +92,15 @@ class ResidentScene:
         return prim, t
 
 
+    def trace_rays_noalloc(self, d_origins, d_directions, d_prim_id, d_t):
+        """rt_hip_trace_rays_noalloc on caller-owned device buffers (anything with data_ptr(): [n,3] f64
+        origins and directions, [n] i32 ids, [n] f64 t, all on this scene's device)."""
+        n = int(d_prim_id.numel())
+        assert d_origins.numel() == 3 * n and d_directions.numel() == 3 * n and d_t.numel() == n
+        abi.check_hip(abi.hip_lib().rt_hip_trace_rays_noalloc(self._h, n, d_origins.data_ptr(), d_directions.data_ptr(),
+                                                              d_prim_id.data_ptr(), d_t.data_ptr()))
+
+
 class RenderIntegrator:
     """Mirror of the reference's RenderIntegrator (integrator.rs:30-36)."""
 

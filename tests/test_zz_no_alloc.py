@@ -1,0 +1,66 @@
+"""rt_hip_trace_rays_noalloc: the closest-hit queries of rt_hip_trace_rays with every working
+buffer in a fixed array of the library's code object.  Same ids and t, bit for bit, on two calls
+in a row (the second smaller: the array still holds the first call's contents), no device memory
+allocated by the calls, and a clear refusal beyond the stated maximum."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+
+from helpers import c1, knot_scene, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_call(torch, res, o, d):
+    n = o.shape[0]
+    d_o = torch.from_numpy(np.ascontiguousarray(o)).cuda()
+    d_d = torch.from_numpy(np.ascontiguousarray(d)).cuda()
+    d_id = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    d_t = torch.full((n,), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    res.trace_rays_noalloc(d_o, d_d, d_id, d_t)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 == free0, "the call changed the amount of free device memory"
+    return d_id.cpu().numpy(), d_t.cpu().numpy()
+
+
+def test_noalloc_queries_equal_trace_rays_on_two_calls_in_a_row(tmp_scene_dir):
+    torch = pytest.importorskip("torch")
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    res = ri.resident(0)
+    for n, seed in ((abi.RT_NOALLOC_MAX_RAYS, 41), (30_001, 42), (1, 43)):
+        o, d = random_rays(n, seed=seed)
+        want_id, want_t = res.trace_rays(o, d)
+        got_id, got_t = _device_call(torch, res, o, d)
+        assert np.array_equal(got_id, want_id), n
+        assert np.array_equal(got_t, want_t), n
+        assert (want_id >= 0).mean() > 0.5 or n == 1
+
+
+def test_noalloc_follows_the_reference_visit_rule_where_the_scene_needs_it():
+    """A scene with quads that stick out of their boxes is walked in two passes: both sets of claim counters are used."""
+    torch = pytest.importorskip("torch")
+    from test_gpu_parity import _tilted_quad_scene
+    ri = _tilted_quad_scene()
+    res = ri.resident(0)
+    for n, seed in ((50_000, 5), (777, 6)):
+        o, d = random_rays(n, seed=seed)
+        want_id, want_t = res.trace_rays(o, d)
+        got_id, got_t = _device_call(torch, res, o, d)
+        assert np.array_equal(got_id, want_id) and np.array_equal(got_t, want_t)
+
+
+def test_noalloc_rejects_sizes_beyond_its_maximum_and_null_buffers():
+    ri = c1(width=8, height=8, batch=1)
+    res = ri.resident(0)
+    lib = abi.hip_lib()
+    rc = lib.rt_hip_trace_rays_noalloc(res._h, abi.RT_NOALLOC_MAX_RAYS + 1, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8))
+    assert rc == abi.RT_ERR_UNSUPPORTED
+    msg = lib.rt_hip_last_error().decode()
+    assert str(abi.RT_NOALLOC_MAX_RAYS) in msg and "at most" in msg
+    assert lib.rt_hip_trace_rays_noalloc(res._h, 5, None, None, None, None) == abi.RT_ERR_BAD_ARG
+    assert lib.rt_hip_trace_rays_noalloc(res._h, 0, None, None, None, None) == abi.RT_OK
