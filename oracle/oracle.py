@@ -75,6 +75,27 @@ def primary_hits(scene_ptr, cfg):
     return prim.reshape(shape), t.reshape(shape)
 
 
+def primary_hits_threads(scene_ptr, cfg, n_threads=8):
+    """primary_hits with the shard's rows dealt to `n_threads` Python threads (the C call releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_rows = cfg.n_rows()
+    n_threads = max(1, min(int(n_threads), n_rows))
+    shape = (n_rows, cfg.img_width, cfg.sample_batch_size)
+    prim = np.empty(shape, dtype=np.int32)
+    t = np.empty(shape, dtype=np.float64)
+
+    def part(k):
+        c = cfg.copy()
+        c.row_first = cfg.row_first + k * cfg.row_stride
+        c.row_stride = cfg.row_stride * n_threads
+        return k, primary_hits(scene_ptr, c)
+
+    with ThreadPoolExecutor(n_threads) as pool:
+        for k, (p, tt) in pool.map(part, range(n_threads)):
+            prim[k::n_threads], t[k::n_threads] = p, tt
+    return prim, t
+
+
 def trace_rays(scene_ptr, origins, directions, want_visits=False):
     o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)

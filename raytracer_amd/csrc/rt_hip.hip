@@ -1007,11 +1007,17 @@ __global__ void __launch_bounds__(256) k_hits_to_elements(DevScene sc, int64_t n
 
 // ================================================================ host side
 struct RtSceneHandle;
-// Working memory of a call, carved out of a grow-only arena owned by the scene handle: the
-// first render pays for hipMalloc, repeated renders (benchmark loops, one render per frame)
-// reuse the same blocks.  One call in flight per handle.
+// Working memory of a call, carved out of an arena owned by the scene handle: the first render
+// pays for hipMalloc, repeated renders (benchmark loops, one render per frame) reuse the block.
+// A render states its needs first (a planning pass over the same allocation code, which only adds
+// up sizes) and the arena is then ONE block of at least that size: a block that is too small is
+// freed and replaced -- never kept beside a second one -- so a handle holds no more than its
+// largest render needed.  The small query entry points allocate without a plan and may add blocks;
+// the next planned call folds them into one again.  One call in flight per handle.
 struct Scratch {
   RtSceneHandle *h;
+  bool planning = false;
+  size_t planned = 0;
   explicit Scratch(RtSceneHandle *handle);
   template <typename T>
   hipError_t alloc(T **out, size_t count) {
@@ -1021,6 +1027,7 @@ struct Scratch {
     return e;
   }
   hipError_t raw(void **out, size_t bytes);
+  hipError_t reserve(size_t bytes);  // after a planning pass: make the arena one block of >= bytes
   hipError_t event(hipEvent_t *out);
 };
 
@@ -1050,6 +1057,11 @@ Scratch::Scratch(RtSceneHandle *handle) : h(handle) {
 }
 hipError_t Scratch::raw(void **out, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
+  if (planning) {
+    planned += bytes;
+    *out = nullptr;
+    return hipSuccess;
+  }
   for (ArenaBlock &b : h->arena) {
     if (b.size - b.used >= bytes) {
       *out = b.base + b.used;
@@ -1063,6 +1075,20 @@ hipError_t Scratch::raw(void **out, size_t bytes) {
   if (e != hipSuccess) return e;
   h->arena.push_back(ArenaBlock{static_cast<char *>(p), size, bytes});
   *out = p;
+  return hipSuccess;
+}
+hipError_t Scratch::reserve(size_t bytes) {
+  planning = false;
+  if (h->arena.size() == 1 && h->arena[0].size >= bytes) return hipSuccess;
+  // no kernel of an earlier call is still running (calls are blocking), so the blocks can go
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return e;
+  for (ArenaBlock &b : h->arena) (void)hipFree(b.base);
+  h->arena.clear();
+  void *p = nullptr;
+  e = hipMalloc(&p, std::max<size_t>(bytes, 256));
+  if (e != hipSuccess) return e;
+  h->arena.push_back(ArenaBlock{static_cast<char *>(p), std::max<size_t>(bytes, 256), 0});
   return hipSuccess;
 }
 hipError_t Scratch::event(hipEvent_t *out) {
@@ -1805,61 +1831,20 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   const uint32_t region_cap = (uint32_t)(((cap_paths + kRegions - 1) / kRegions + 63) / 64 * 64);
   const size_t q_entries = (size_t)region_cap * kRegions;
   PathQueue q[2];
-  for (int k = 0; k < 2; k++) {
-    HIP_TRY(sc.alloc(&q[k].ox, q_entries)); HIP_TRY(sc.alloc(&q[k].oy, q_entries)); HIP_TRY(sc.alloc(&q[k].oz, q_entries));
-    HIP_TRY(sc.alloc(&q[k].dx, q_entries)); HIP_TRY(sc.alloc(&q[k].dy, q_entries)); HIP_TRY(sc.alloc(&q[k].dz, q_entries));
-    HIP_TRY(sc.alloc(&q[k].tx, q_entries)); HIP_TRY(sc.alloc(&q[k].ty, q_entries)); HIP_TRY(sc.alloc(&q[k].tz, q_entries));
-    HIP_TRY(sc.alloc(&q[k].rng, q_entries));
-    HIP_TRY(sc.alloc(&q[k].pid, q_entries));
-    q[k].cap = region_cap;
-  }
   HitBuffer hits;
-  HIP_TRY(sc.alloc(&hits.t, q_entries));
-  HIP_TRY(sc.alloc(&hits.ref, q_entries));
   PathResults results;
   double *weights, *sums, *hist = nullptr;
-  HIP_TRY(sc.alloc(&results.rec, cap_paths));
-  HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)n_pix));
-  HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
-  // per-batch (illuminance_approx, weight) history, needed only if the z-test can ever run
-  if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)n_pix));
   uint32_t *active[2], *counters;
-  HIP_TRY(sc.alloc(&active[0], n_pix));
-  HIP_TRY(sc.alloc(&active[1], n_pix));
   // counters (each on its own 128-byte line): [0] next_count; then per bounce 0..max_depth the
   // kRegions queue sizes; then per bounce the kRegions work-claim counters of k_extend, twice
   // (a tree with stray primitives is walked in two launches per bounce, each claiming the whole queue)
   const size_t per_bounce = (size_t)kRegions * kCounterStride;
   const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
-  HIP_TRY(sc.alloc(&counters, n_counters));
-  uint32_t *qcounts = counters + kCounterStride;
-  uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
-  uint32_t *work2 = work + (size_t)rp.max_depth * per_bounce;
-  const int walk = walk_mode(h, rp.flags);
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
   constexpr int kTotals = RT_MAX_DEPTH_STATS + 6;
   unsigned long long *totals;
-  HIP_TRY(sc.alloc(&totals, kTotals));
-  HIP_TRY(hipMemsetAsync(totals, 0, kTotals * sizeof(unsigned long long), st));
-
   PixelOutputs po{};
-  if (out->memory == RT_MEM_DEVICE) {
-    po.pixels = out->pixels;
-    po.sample_pixels = out->sample_pixels;
-    po.linear = out->linear;
-    po.samples = out->samples;
-    po.rgb8 = out->rgb8;
-    po.sample_rgb8 = out->sample_rgb8;
-  } else {
-    HIP_TRY(sc.alloc(&po.pixels, 3 * (size_t)n_pix));
-    if (out->sample_pixels) HIP_TRY(sc.alloc(&po.sample_pixels, 3 * (size_t)n_pix));
-    if (out->linear) HIP_TRY(sc.alloc(&po.linear, 3 * (size_t)n_pix));
-    if (out->samples) HIP_TRY(sc.alloc(&po.samples, (size_t)n_pix));
-    if (out->rgb8) HIP_TRY(sc.alloc(&po.rgb8, 3 * (size_t)n_pix));
-    if (out->sample_rgb8) HIP_TRY(sc.alloc(&po.sample_rgb8, 3 * (size_t)n_pix));
-  }
-
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
   // the list is sorted by key again after every round that drops pixels, because the order of
   // the pixels is the order of the rays in every queue: consecutive keys are the pixels of one
@@ -1867,9 +1852,58 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   size_t sort_bytes = 0;
   int sort_bits = 1;
   while (sort_bits < 32 && (1ll << sort_bits) < ((int64_t)rp.n_tiles << (2 * kTileLog))) sort_bits++;
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, active[0], active[1], n_pix, 0, sort_bits, st));
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, n_pix, 0, sort_bits, st));
   void *sort_tmp = nullptr;
-  HIP_TRY(sc.raw(&sort_tmp, sort_bytes));
+  // every buffer of the render; run once to add up the sizes, then for real on the reserved block
+  auto allocate = [&]() -> int {
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(sc.alloc(&q[k].ox, q_entries)); HIP_TRY(sc.alloc(&q[k].oy, q_entries)); HIP_TRY(sc.alloc(&q[k].oz, q_entries));
+      HIP_TRY(sc.alloc(&q[k].dx, q_entries)); HIP_TRY(sc.alloc(&q[k].dy, q_entries)); HIP_TRY(sc.alloc(&q[k].dz, q_entries));
+      HIP_TRY(sc.alloc(&q[k].tx, q_entries)); HIP_TRY(sc.alloc(&q[k].ty, q_entries)); HIP_TRY(sc.alloc(&q[k].tz, q_entries));
+      HIP_TRY(sc.alloc(&q[k].rng, q_entries));
+      HIP_TRY(sc.alloc(&q[k].pid, q_entries));
+      q[k].cap = region_cap;
+    }
+    HIP_TRY(sc.alloc(&hits.t, q_entries));
+    HIP_TRY(sc.alloc(&hits.ref, q_entries));
+    HIP_TRY(sc.alloc(&results.rec, cap_paths));
+    HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)n_pix));
+    HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
+    // per-batch (illuminance_approx, weight) history, needed only if the z-test can ever run
+    if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)n_pix));
+    HIP_TRY(sc.alloc(&active[0], n_pix));
+    HIP_TRY(sc.alloc(&active[1], n_pix));
+    HIP_TRY(sc.alloc(&counters, n_counters));
+    HIP_TRY(sc.alloc(&totals, kTotals));
+    if (out->memory == RT_MEM_DEVICE) {
+      po.pixels = out->pixels;
+      po.sample_pixels = out->sample_pixels;
+      po.linear = out->linear;
+      po.samples = out->samples;
+      po.rgb8 = out->rgb8;
+      po.sample_rgb8 = out->sample_rgb8;
+    } else {
+      HIP_TRY(sc.alloc(&po.pixels, 3 * (size_t)n_pix));
+      if (out->sample_pixels) HIP_TRY(sc.alloc(&po.sample_pixels, 3 * (size_t)n_pix));
+      if (out->linear) HIP_TRY(sc.alloc(&po.linear, 3 * (size_t)n_pix));
+      if (out->samples) HIP_TRY(sc.alloc(&po.samples, (size_t)n_pix));
+      if (out->rgb8) HIP_TRY(sc.alloc(&po.rgb8, 3 * (size_t)n_pix));
+      if (out->sample_rgb8) HIP_TRY(sc.alloc(&po.sample_rgb8, 3 * (size_t)n_pix));
+    }
+    HIP_TRY(sc.raw(&sort_tmp, sort_bytes));
+    return RT_OK;
+  };
+  sc.planning = true;
+  rc = allocate();
+  if (rc != RT_OK) return rc;
+  HIP_TRY(sc.reserve(sc.planned));
+  rc = allocate();
+  if (rc != RT_OK) return rc;
+  uint32_t *qcounts = counters + kCounterStride;
+  uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
+  uint32_t *work2 = work + (size_t)rp.max_depth * per_bounce;
+  const int walk = walk_mode(h, rp.flags);
+  HIP_TRY(hipMemsetAsync(totals, 0, kTotals * sizeof(unsigned long long), st));
 
   const int block = 256;
   const int max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups

@@ -34,3 +34,85 @@ def random_rays(n, seed=0):
     o[:k] = np.array([278.0, 278.0, -800.0]) + rng.normal(scale=3.0, size=(k, 3))
     d[:k] = rng.uniform(0.0, 555.0, size=(k, 3)) * np.array([1.0, 1.0, 0.0]) - o[:k]
     return o, d
+
+
+# ------------------------------------------------------------ the reference's own input files
+# Data the reference ships (input/scene_teapot.json, input/config.json, input/obj/teapot.obj,
+# input/obj/diamond.obj), kept under tests/golden/ref_inputs as inputs for the loader and the renders.
+REF_INPUTS = os.path.join(GOLDEN, "ref_inputs")
+
+
+def ref_config(**overrides):
+    """input/config.json (600x600, batches of 20, up to 500, SAH, gamma 2.4) with fields replaced."""
+    import json
+    with open(os.path.join(REF_INPUTS, "config.json")) as f:
+        cfg = json.load(f)
+    cfg.update(overrides)
+    return cfg
+
+
+def teapot_scene(width, height, batch, max_batches, min_batches):
+    """input/scene_teapot.json: teapot.obj (6 320 triangles, scaled, rotated, moved) + metal box + walls +
+    quad light (attractor), with input/config.json resized."""
+    import json
+    with open(os.path.join(REF_INPUTS, "scene_teapot.json")) as f:
+        scene = json.load(f)
+    cfg = ref_config(img_width=float(width), img_height=float(height), sample_batch_size=int(batch),
+                     max_sample_batches=int(max_batches), min_sample_batches=int(min_batches))
+    return RenderIntegrator.new(scene, cfg, base_dir=REF_INPUTS).prepare()
+
+
+# ------------------------------------------------------------------------------ image gates
+# Device and oracle draw the same per-path random streams, so their linear images agree to rounding
+# except where a last-bit difference in sin / cos / pow flips a path across an edge.  Measured on
+# every BASELINE configuration: all pixels equal.  The gates leave room for one such pixel in a thousand
+# and bound what it may do to the image.
+PIXEL_GATE = 0.999        # share of pixels whose linear radiance equals the oracle's to 1e-9
+COUNT_GATE = 0.999        # share of pixels that stop at the oracle's sample count
+RMSE_EQUAL_GATE = 1e-9    # RMSE of the linear radiance over the pixels that agree
+RMSE_NOISE_SHARE = 0.05   # RMSE over ALL pixels <= this share of the image's own Monte-Carlo noise, i.e. of the
+                          # RMSE between two device renders with different seeds (a flipped path changes one
+                          # sample of one pixel; the noise is what all samples of all pixels scatter by)
+
+
+def image_parity(out_g, out_o):
+    lg, lo = out_g["linear"], out_o["linear"]
+    finite = np.isfinite(lo) & np.isfinite(lg)
+    close = (np.isclose(lg, lo, rtol=1e-9, atol=1e-9, equal_nan=True) | ((lg == lo) & ~finite)).all(axis=-1)
+    diff = np.where(finite, lg - lo, 0.0)
+    same_counts = (out_g["samples"] == out_o["samples"]) if "samples" in out_g and "samples" in out_o else np.ones(close.shape, bool)
+    rmse_equal = float(np.sqrt((diff[close] ** 2).mean())) if close.any() else 0.0
+    return {"equal": float(close.mean()), "counts": float(same_counts.mean()), "rmse": float(np.sqrt((diff ** 2).mean())),
+            "rmse_equal_pixels": rmse_equal, "worst": float(np.abs(diff).max()), "n": int(close.size), "n_differ": int((~close).sum())}
+
+
+def assert_image_parity(out_g, out_o, what="", res=None, cfg=None, noise_share=RMSE_NOISE_SHARE):
+    """The gates above.  `res`, `cfg`: the resident scene and the configuration `out_g` was rendered with;
+    needed only when some pixel differs, to measure the image's noise with a second seed."""
+    p = image_parity(out_g, out_o)
+    msg = f"{what}: {p}"
+    assert p["equal"] >= PIXEL_GATE, msg
+    assert p["counts"] >= COUNT_GATE, msg
+    assert p["rmse_equal_pixels"] <= RMSE_EQUAL_GATE, msg
+    if p["rmse"] > RMSE_EQUAL_GATE:
+        assert res is not None and cfg is not None, "pixels differ and no scene was given to measure the noise: " + msg
+        other = cfg.copy()
+        other.seed = cfg.seed ^ 0x5EED5EED
+        out_b, _ = res.render(other)
+        lg, lb = out_g["linear"], out_b["linear"]
+        finite = np.isfinite(lg) & np.isfinite(lb)
+        noise = float(np.sqrt((np.where(finite, lg - lb, 0.0) ** 2).mean()))
+        p["noise_rmse"] = noise
+        assert p["rmse"] <= noise_share * noise, f"{what}: {p}"
+    return p
+
+
+def noise_gate(gpu_a, gpu_b, ref, factor):
+    """The statistical gate against the reference's own random-number mode (one xoshiro256++ per row: a
+    different sample sequence, so only statistics can agree).  RMSE(gpu, ref) must not exceed `factor` x
+    RMSE(gpu seed A, gpu seed B): two independent estimates at the same sample counts differ by pure
+    Monte-Carlo noise, and an unbiased device image differs from the reference's by no more."""
+    rmse_ref = float(np.sqrt(((gpu_a - ref) ** 2).mean()))
+    rmse_self = float(np.sqrt(((gpu_a - gpu_b) ** 2).mean()))
+    assert rmse_ref <= factor * rmse_self, (rmse_ref, rmse_self, factor)
+    return rmse_ref, rmse_self

@@ -7,7 +7,7 @@ ray), triangles (some degenerate, some duplicated, some coplanar with a quad), o
 import numpy as np
 import pytest
 
-from helpers import random_rays
+from helpers import assert_image_parity, random_rays
 from oracle import oracle
 from raytracer_amd import RenderIntegrator, scenes
 
@@ -95,8 +95,7 @@ def test_random_scene_images(seed):
     cfg.sample_batch_size, cfg.max_sample_batches, cfg.min_sample_batches = 8, 4, 0
     out_g, st_g = ri.resident(0).render(cfg)
     out_o, st_o = oracle.render(ri.scene, cfg, 8)
-    lg, lo = out_g["linear"], out_o["linear"]
-    close = (np.isclose(lg, lo, rtol=1e-9, atol=1e-9, equal_nan=True) | ((lg == lo) & np.isinf(lg))).all(axis=-1)
-    assert close.mean() >= 0.98, f"seed {seed}: only {close.mean():.4f} of the pixels agree"
-    assert (out_g["samples"] == out_o["samples"]).mean() >= 0.98
-    assert abs(int(st_g.rays) - int(st_o.rays)) <= 5e-3 * st_o.rays + 50
+    # 1 600 pixels at 32 spp under lights of radiance up to 10: ONE flipped path that ends on a light is a tenth of
+    # so small an image's whole noise, hence the wider share here (the gates on pixel and sample counts stay)
+    assert_image_parity(out_g, out_o, f"seed {seed}", ri.resident(0), cfg, noise_share=0.25)
+    assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays + 8

@@ -14,7 +14,7 @@ import pytest
 from raytracer_amd import abi
 from oracle import oracle
 
-from helpers import c1, knot_scene, random_rays
+from helpers import assert_image_parity, c1, knot_scene, noise_gate, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -196,9 +196,8 @@ def test_soup_scene_with_glass_and_metal_triangles(tmp_scene_dir):
     assert np.array_equal(pg, po) and np.array_equal(tg, to)
     out_g, st_g = res.render(cfg)
     out_o, st_o = oracle.render(ri.scene, cfg, 8)
-    frac, rmse, worst = _image_checks(out_g, st_g, out_o, st_o, cfg)
-    assert frac >= 0.98, f"only {frac:.4f} of pixels agree to 1e-9 (rmse {rmse:.3e}, worst {worst:.3e})"
-    assert abs(int(st_g.rays) - int(st_o.rays)) <= 2e-3 * st_o.rays
+    assert_image_parity(out_g, out_o, "20 000-triangle soup", res, cfg)
+    assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
 
 
 def _tilted_quad_scene():
@@ -251,14 +250,6 @@ def test_two_pass_walk_equals_reference_rule_alone():
     assert np.array_equal(pg, po) and np.array_equal(tg, to)
 
 
-def _image_checks(out_g, st_g, out_o, st_o, cfg, tight=1e-9):
-    lin_g, lin_o = out_g["linear"], out_o["linear"]
-    close = np.isclose(lin_g, lin_o, rtol=1e-9, atol=tight).all(axis=-1)
-    diff = np.abs(lin_g - lin_o)
-    rmse = float(np.sqrt((diff ** 2).mean()))
-    return close.mean(), rmse, diff.max()
-
-
 def test_render_matches_oracle_counter_mode():
     """Same per-path random streams on both sides: the images agree to rounding except
     where a last-bit difference in sin/cos/pow flips a path across an edge."""
@@ -266,13 +257,12 @@ def test_render_matches_oracle_counter_mode():
     cfg = ri.config.copy()
     out_g, st_g = ri.resident(0).render(cfg)
     out_o, st_o = oracle.render(ri.scene, cfg, 8)
-    frac, rmse, worst = _image_checks(out_g, st_g, out_o, st_o, cfg)
-    assert frac >= 0.99, f"only {frac:.4f} of pixels agree to 1e-9 (rmse {rmse:.3e}, worst {worst:.3e})"
+    assert_image_parity(out_g, out_o, "C1 64x64x16", ri.resident(0), cfg)
     assert np.array_equal(out_g["samples"], out_o["samples"])
-    assert np.allclose(out_g["sample_pixels"], out_o["sample_pixels"])
-    assert np.isclose(out_g["pixels"], out_o["pixels"], atol=1e-6).all(axis=-1).mean() >= 0.99
-    # ray counts: identical decisions -> identical counts (up to the few flipped paths)
-    assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-3 * st_o.rays
+    assert np.array_equal(out_g["sample_pixels"], out_o["sample_pixels"])
+    assert np.isclose(out_g["pixels"], out_o["pixels"], atol=1e-9).all(axis=-1).mean() >= 0.999
+    # ray counts: identical decisions -> identical counts (up to a flipped path)
+    assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
     assert st_g.samples == st_o.samples == 64 * 64 * 16
 
 
@@ -282,37 +272,30 @@ def test_render_adaptive_matches_oracle_counter_mode(tmp_scene_dir):
     cfg = ri.config.copy()
     out_g, st_g = ri.resident(0).render(cfg)
     out_o, st_o = oracle.render(ri.scene, cfg, 8)
-    same_counts = (out_g["samples"] == out_o["samples"]).mean()
-    assert same_counts >= 0.99, same_counts
-    ok = out_g["samples"] == out_o["samples"]
-    close = np.isclose(out_g["linear"], out_o["linear"], rtol=1e-9, atol=1e-9).all(axis=-1)
-    assert close[ok].mean() >= 0.98
+    assert_image_parity(out_g, out_o, "adaptive 2 000-triangle knot", ri.resident(0), cfg)
     # the adaptive loop really is exercised: some pixels stop early, some run to the end
     assert out_g["samples"].min() < out_g["samples"].max()
     assert out_g["samples"].max() == 8 * 12 and out_g["samples"].min() >= 8 * 4
 
 
 def test_render_vs_reference_rng_within_noise():
-    """Against the oracle in the reference's own RNG mode (one xoshiro256++ per row)
-    only the statistics can agree.  Per-pixel bound: 4 sigma of the difference of two
-    independent N-sample means, sigma estimated from two oracle runs with different
-    row seeds is not available in the reference, so the bound is taken from the
-    spread between the oracle's two modes, which are independent estimates too."""
-    ri = c1(width=40, height=40, batch=64, max_batches=1, min_batches=1)
+    """Against the oracle in the reference's own RNG mode (one xoshiro256++ per row) only the
+    statistics can agree: the device's image must differ from it by no more than two device
+    renders with different seeds differ from each other (pure Monte-Carlo noise), and the means
+    must agree.  64 spp, 48x48: the RMSE ratio of such a small image scatters by a few percent."""
+    ri = c1(width=48, height=48, batch=64, max_batches=1, min_batches=1)
     cfg = ri.config.copy()
-    out_g, _ = ri.resident(0).render(cfg)
+    out_a, _ = ri.resident(0).render(cfg)
+    other = cfg.copy()
+    other.seed = 12345
+    out_b, _ = ri.resident(0).render(other)
     ref = cfg.copy()
     ref.rng_mode = abi.RT_RNG_REF
     out_r, _ = oracle.render(ri.scene, ref, 8)
-    ctr = cfg.copy()
-    ctr.seed = 12345
-    out_c, _ = oracle.render(ri.scene, ctr, 8)
-    lum = lambda a: (a * np.array([0.2126, 0.7152, 0.0722])).sum(-1)
-    noise = np.sqrt(((lum(out_c["linear"]) - lum(out_r["linear"])) ** 2).mean())
-    rmse = np.sqrt(((lum(out_g["linear"]) - lum(out_r["linear"])) ** 2).mean())
-    assert rmse <= 1.25 * noise + 1.0 / 255.0, (rmse, noise)
-    # unbiased: image means agree to a few percent
-    assert abs(out_g["linear"].mean() - out_r["linear"].mean()) <= 0.03 * out_r["linear"].mean()
+    rmse_ref, rmse_self = noise_gate(out_a["linear"], out_b["linear"], out_r["linear"], 1.15)
+    assert rmse_self > 0.0
+    # unbiased: image means agree to a few percent at this sample count
+    assert abs(out_a["linear"].mean() - out_r["linear"].mean()) <= 0.03 * out_r["linear"].mean()
 
 
 def test_render_is_deterministic_and_tiling_independent():
@@ -344,8 +327,7 @@ def test_odd_image_shapes_match_the_oracle(width, height, stride):
         out_o, st_o = oracle.render(ri.scene, cfg, 4)
         assert out_g["linear"].shape == out_o["linear"].shape
         assert np.array_equal(out_g["samples"], out_o["samples"])
-        frac, rmse, worst = _image_checks(out_g, st_g, out_o, st_o, cfg)
-        assert frac >= 0.97 or worst < 1e-6, (frac, worst)
+        assert_image_parity(out_g, out_o, f"{width}x{height} rows {first}::{stride}", ri.resident(0), cfg)
         assert st_g.samples == st_o.samples
 
 
@@ -512,3 +494,38 @@ def test_device_output_buffers():
     assert np.array_equal(dev["pixels"].cpu().numpy(), a["pixels"])
     assert np.array_equal(dev["linear"].cpu().numpy(), a["linear"])
     assert np.array_equal(dev["samples"].cpu().numpy().astype(np.uint32), a["samples"])
+
+
+def test_working_memory_of_a_handle_is_what_its_largest_render_needed():
+    """A small shard first, then the whole image, then both again: the handle must end up holding one
+    working block sized for the whole image -- not the shard's blocks beside a second full set -- and
+    later renders must reuse it."""
+    torch = pytest.importorskip("torch")
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    ri = c1(width=512, height=512, batch=16, max_batches=4, min_batches=1)
+    res = ri.resident(0)
+    whole = ri.config.copy()
+    shard = whole.copy()
+    shard.row_first, shard.row_stride = 3, 8
+    f0 = free_bytes()
+    s, _ = res.render(shard)
+    f1 = free_bytes()
+    a, _ = res.render(whole)
+    f2 = free_bytes()
+    s2, _ = res.render(shard)
+    f3 = free_bytes()
+    b, _ = res.render(whole)
+    f4 = free_bytes()
+    assert f0 - f2 > f0 - f1 > 0
+    assert f3 == f2 and f4 == f2
+    other = c1(width=512, height=512, batch=16, max_batches=4, min_batches=1)
+    res2 = other.resident(0)
+    g0 = free_bytes()
+    res2.render(other.config.copy())
+    g1 = free_bytes()
+    assert f0 - f2 <= (g0 - g1) + (4 << 20), (f0 - f2, g0 - g1)
+    assert np.array_equal(a["linear"], b["linear"]) and np.array_equal(s["linear"], s2["linear"]) and np.array_equal(s["linear"], a["linear"][3::8])

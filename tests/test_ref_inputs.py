@@ -1,0 +1,79 @@
+"""The reference's own input files (kept as data under tests/golden/ref_inputs) through the C++ host:
+input/config.json, input/scene_teapot.json + input/obj/teapot.obj (BASELINE configs[1]) and
+input/obj/diamond.obj (`g` groups, exponent notation, runs of blanks after `f`).  The loader restates
+elements/obj.rs:27-103 over the wavefront_obj crate (per-object vertex lists, fan triangulation)."""
+import json
+import os
+
+import numpy as np
+
+from raytracer_amd import RenderIntegrator, abi, scenes
+from oracle import host_ref
+
+from helpers import REF_INPUTS, ref_config, teapot_scene
+
+
+def test_config_json_of_the_reference():
+    """config.rs:8-20: img_width / img_height are f64 in the file, the split method is an Option."""
+    raw = json.load(open(os.path.join(REF_INPUTS, "config.json")))
+    assert isinstance(raw["img_width"], float) and raw["img_width"] == 600.0 and raw["bvh_split_method"] == "SAH"
+    ri = RenderIntegrator.new({"camera": scenes.camera(), "elements": scenes.cornell_elements()}, raw)
+    cfg = ri.config
+    assert (cfg.img_width, cfg.img_height) == (600, 600)
+    assert (cfg.sample_batch_size, cfg.max_sample_batches, cfg.min_sample_batches, cfg.max_depth) == (20, 500, 2, 8)
+    assert cfg.pixel_radius == 2.0 and cfg.gamma_correction == 2.4
+    assert cfg.filter_b == 1.0 / 3.0 and cfg.filter_c == 1.0 / 3.0  # integrator.rs:47-52
+    ri.prepare()
+    # SAH and Mid give different trees on this scene: the file's method is the one in use
+    mid = dict(raw)
+    mid["bvh_split_method"] = "Mid"
+    rm = RenderIntegrator.new({"camera": scenes.camera(), "elements": scenes.cornell_elements()}, mid).prepare()
+    a = [(n.is_leaf, n.element_index) for n in (ri.scene.contents.nodes[i] for i in range(ri.scene.contents.n_nodes))]
+    b = [(n.is_leaf, n.element_index) for n in (rm.scene.contents.nodes[i] for i in range(rm.scene.contents.n_nodes))]
+    assert a != b
+
+
+def test_teapot_scene_of_the_reference_loads():
+    ri = teapot_scene(64, 64, 4, 1, 1)
+    sc = ri.scene.contents
+    # 6 320 faces of teapot.obj + 12 box triangles + 12 wall triangles, one quad light
+    assert sc.n_triangles == 6320 + 12 + 12 and sc.n_quads == 1 and sc.n_spheres == 0
+    assert sc.n_elements == 6345 and sc.n_nodes == 2 * 6345 - 1
+    assert [sc.attractors[i] for i in range(sc.n_attractors)] == [6344]
+    assert sc.elements[0].kind == abi.RT_PRIM_TRIANGLE and sc.elements[6344].kind == abi.RT_PRIM_QUAD
+    # first face `f 2909 2921 2939`: vertices scaled by 20, rotated about y by -3.2, moved by (220, 0, 200)
+    scene = json.load(open(os.path.join(REF_INPUTS, "scene_teapot.json")))
+    scene["elements"][0]["JSONObj"]["filepath"] = os.path.join(REF_INPUTS, "obj", "teapot.obj")
+    ref = host_ref.build_scene(scene, ref_config())
+    assert len(ref["triangles"]) == sc.n_triangles
+    for k in (0, 1, 3000, 6319, 6320, 6343):
+        t, r = sc.triangles[k], ref["triangles"][k]
+        assert t.v0.tuple() == r["v0"] and t.v0v1.tuple() == r["v0v1"] and t.v0v2.tuple() == r["v0v2"] and t.normal.tuple() == r["normal"], k
+    # the whole SAH tree equals the independent Python build
+    nodes = [(n.is_leaf, n.element_index, n.child_l_index, n.child_r_index, tuple(n.child_l_min), tuple(n.child_l_max),
+              tuple(n.child_r_min), tuple(n.child_r_max)) for n in (sc.nodes[i] for i in range(sc.n_nodes))]
+    assert nodes == ref["nodes"]
+    # the teapot stands on the floor inside the room
+    lo = np.min([ri.element_bbox(i)[0] for i in range(6320)], axis=0)
+    hi = np.max([ri.element_bbox(i)[1] for i in range(6320)], axis=0)
+    assert (lo > [100, -1e-3, 100]).all() and (hi < [350, 80, 300]).all()
+
+
+def test_diamond_obj_of_the_reference_loads():
+    """`g Object001`, `0.000000E+00`, `f     1 2 3`."""
+    path = os.path.join(REF_INPUTS, "obj", "diamond.obj")
+    scene = {"camera": scenes.camera(), "elements": [scenes.obj_element(path, scenes.dielectric(1.5))]}
+    ri = RenderIntegrator.new(scene, ref_config()).prepare()
+    sc = ri.scene.contents
+    faces = [l.split()[1:] for l in open(path) if l.startswith("f")]
+    verts = [[float(x) for x in l.split()[1:]] for l in open(path) if l.startswith("v ")]
+    assert len(verts) == 6 and verts[0] == [0.0, 0.0, 78.0]
+    assert sc.n_triangles == len(faces) == 9
+    for k, f in enumerate(faces):
+        a, b, c = (np.array(verts[int(i) - 1]) for i in f)
+        t = sc.triangles[k]
+        assert t.v0.tuple() == tuple(a) and t.v0v1.tuple() == tuple(b - a) and t.v0v2.tuple() == tuple(c - a)
+    ref = host_ref.build_scene(scene, ref_config())
+    nodes = [(n.is_leaf, n.element_index, n.child_l_index, n.child_r_index, tuple(n.child_l_min), tuple(n.child_l_max),
+              tuple(n.child_r_min), tuple(n.child_r_max)) for n in (sc.nodes[i] for i in range(sc.n_nodes))]
+    assert nodes == ref["nodes"]
