@@ -7,15 +7,19 @@ adaptive sampling -- BASELINE.json configs[2].
 
 One "step" = one full render of that image (scene already resident in HBM):
 time-to-image.  value = BVH closest-hit queries per second (Mrays/s) summed
-over all ranks.  With --gpus N (launched by torch.distributed.run, one
-process per GPU) the rows of the SAME image are dealt round-robin over the
-ranks and gathered to rank 0 with RCCL: total work is fixed ("strong").
+over all ranks.  With --gpus N the rows of the SAME image are dealt over N
+ranks (one process per GPU) and gathered to rank 0 with one RCCL collective:
+total work is fixed ("strong").  `python bench.py --gpus N` typed as such starts
+the N ranks itself (torch.distributed.run as a child process, before anything
+touches the GPU); under torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -23,19 +27,97 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-NODE_BYTES = 64        # device BVH node: two f32 child boxes + two refs
-TRI_BYTES = 80         # device triangle record: v0, e1, e2 (f64) + ids
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (measured figure of the MI355X guide)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+NODE_BYTES = 64         # the byte model's node: two f32 child boxes + two refs (the device reads a 32-byte grid form)
+TRI_BYTES = 80          # device triangle record: v0, e1, e2 (f64) + ids
 RAY_STATE_BYTES = 48 + 12  # k_extend reads origin + direction (6 f64), writes t + ref
-# HBM/fabric bytes per ray of k_extend measured with rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
-# on this same workload; produced by tools/summarize_profiles.py from separate counter runs.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")
+# Counter sums per kernel of ONE render of this workload (separate rocprofv3 --pmc passes of this file, condensed
+# by tools/summarize_profiles.py): what the roofline figures that no event can measure are derived from.
+ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=1200)
+    ap.add_argument("--triangles", type=int, default=100_000)
+    ap.add_argument("--batch", type=int, default=20, help="sample_batch_size (other sizes are not the headline workload)")
+    ap.add_argument("--max-batches", type=int, default=100)
+    ap.add_argument("--min-batches", type=int, default=2)
+    ap.add_argument("--row-block", type=int, default=None, help="rows dealt together to a rank (default: raytracer_amd.parallel.ROW_BLOCK)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--early-terminate", action="store_true", help="set RT_FLAG_EARLY_TERMINATE (same pixels, fewer rays)")
+    ap.add_argument("--reference-visits", action="store_true", help="set RT_FLAG_REFERENCE_VISIT_RULE (same pixels, more node visits)")
+    ap.add_argument("--profile-pass", action="store_true",
+                    help="exactly one render and nothing else on the GPU (for rocprofv3 counter passes): implies --steps 1 --warmup 0, "
+                         "no CPU baseline, no instrumented render")
+    ap.add_argument("--dry-run", action="store_true", help="print the launch plan (child command and environment) and exit")
+    args = ap.parse_args(argv)
+    if args.profile_pass:
+        args.steps, args.warmup, args.no_cpu_baseline = 1, 0, True
+    return args
+
+
+def spawn_plan(args, argv):
+    """The child command that starts `args.gpus` ranks of this file, one per GPU, and the environment it adds."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
+    env = {"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    return cmd, env
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside a launcher: run the ranks as children of a process that has not touched the
+    GPU, relay rank 0's JSON line and the children's exit code."""
+    cmd, env = spawn_plan(args, argv)
+    if args.dry_run:
+        print(json.dumps({"spawn": cmd, "env": env, "ranks": args.gpus}))
+        return 0
+    p = subprocess.run(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in p.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return p.returncode if p.returncode else (0 if lines else 1)
+
+
+def host_cpu():
+    """Cores this process may use (affinity mask, and OMP_NUM_THREADS where the box sets its share that way) and the CPU model."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    share = visible
+    try:
+        share = max(1, min(visible, int(os.environ.get("OMP_NUM_THREADS", visible))))
+    except ValueError:
+        pass
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"threads_used": share, "affinity_cpus": visible, "os_cpu_count": os.cpu_count(), "model": model}
 
 
 def rust_crate_check():
     """bindings/rust/rt-hip-sys is written without a Rust toolchain: if this machine has one, type-check it."""
     import shutil
-    import subprocess
     cargo = shutil.which("cargo")
     if not cargo:
         return {"cargo": None, "checked": False}
@@ -47,22 +129,48 @@ def rust_crate_check():
         return {"cargo": cargo, "checked": False, "error": str(e)}
 
 
+def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
+    """Roofline figures of the two dominant kernels from the committed counter sums (per ray of the profiled render)
+    and this run's event times.  Formulas (Measurement):
+      VALU busy  = 4 * SQ_ACTIVE_INST_VALU / (N_SIMD * GRBM_GUI_ACTIVE / 8)        [SQ counts quad-cycles; GRBM sums 8 XCDs]
+      k_extend   bound "valu-issue": frac = VALU busy * share of lanes doing useful work in a wave's steps
+      fabric B/s = (FETCH_SIZE * fetch_factor + WRITE_SIZE) KiB * 1024 / kernel time  -> hbm_frac against 8 TB/s
+      L2 B/s     = (TCC_HIT + TCC_MISS) * 128 B / kernel time                        -> l2_frac against 34.5 TB/s
+    """
+    out = {}
+    prof_rays = inputs["rays"]
+    ff = inputs.get("fetch_factor", 2.0)
+    for name, ms in (("k_extend", extend_ms), ("k_shade", shade_ms)):
+        c = inputs["kernels"].get(name)
+        if not c or ms <= 0:
+            continue
+        scale = rays / prof_rays  # counters scale with the rays traced
+        t = ms * 1e-3
+        fabric = (c["FETCH_SIZE"] * ff + c["WRITE_SIZE"]) * 1024.0 * scale
+        l2 = (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * 128.0 * scale
+        valu_busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8.0)
+        out[name] = {
+            "fabric_bytes": fabric, "fabric_GBs": fabric / t / 1e9, "hbm_frac": fabric / t / 1e9 / HBM_PEAK_GBS,
+            "l2_GBs": l2 / t / 1e9, "l2_frac": l2 / t / 1e9 / L2_PEAK_GBS,
+            "l2_hit_rate": c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0),
+            "valu_busy": valu_busy,
+            "wait_share_of_wave_time": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
+            "profiled_avg_launch_ms": c.get("kernel_avg_launch_ms"), "this_run_kernel_ms": ms,
+        }
+    if "k_extend" in out:
+        out["k_extend"]["useful_lane_share"] = lanes_useful
+        out["k_extend"]["valu_issue_frac"] = out["k_extend"]["valu_busy"] * lanes_useful
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1200)
-    ap.add_argument("--height", type=int, default=1200)
-    ap.add_argument("--triangles", type=int, default=100_000)
-    ap.add_argument("--batch", type=int, default=20, help="sample_batch_size (other sizes are not the headline workload)")
-    ap.add_argument("--max-batches", type=int, default=100)
-    ap.add_argument("--min-batches", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU-baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--early-terminate", action="store_true", help="set RT_FLAG_EARLY_TERMINATE (same pixels, fewer rays)")
-    ap.add_argument("--reference-visits", action="store_true", help="set RT_FLAG_REFERENCE_VISIT_RULE (same pixels, more node visits)")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_run:
+        print(json.dumps({"spawn": None, "ranks": int(os.environ.get("WORLD_SIZE", "1"))}))
+        return
 
     import torch
     import torch.distributed as dist
@@ -72,14 +180,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    row_block = parallel.ROW_BLOCK if args.row_block is None else max(1, args.row_block)
 
     # ---- inputs (not timed): generated mesh + scene/config JSON, then the reference's host steps
     workdir = os.path.join(tempfile.gettempdir(), f"rt_bench_{os.getuid()}_{rank}")
@@ -92,35 +200,28 @@ def main():
     res = ri.resident(local_rank)
     t_upload = time.time() - t_up0
     sc = ri.scene.contents
-    cfg = parallel.shard_config(ri.config, rank, world)
+    cfg = parallel.shard_config(ri.config, rank, world, row_block)
     opt_flags = (abi.RT_FLAG_EARLY_TERMINATE if args.early_terminate else 0) | (abi.RT_FLAG_REFERENCE_VISIT_RULE if args.reference_visits else 0)
     cfg.flags = abi.RT_FLAG_TIME_KERNELS | opt_flags
     H, W = cfg.img_height, cfg.img_width
     n_rows = cfg.n_rows()
     dev = torch.device("cuda", local_rank)
-    out = {
-        "pixels": torch.empty(n_rows, W, 3, dtype=torch.float64, device=dev),
-        "sample_pixels": torch.empty(n_rows, W, 3, dtype=torch.float64, device=dev),
-        "samples": torch.empty(n_rows, W, dtype=torch.int32, device=dev),
-    }
+    # image and heat-map are two planes of one buffer, so that one collective moves both
+    planes = torch.empty(2, n_rows, W, 3, dtype=torch.float64, device=dev)
+    out = {"pixels": planes[0], "sample_pixels": planes[1], "samples": torch.empty(n_rows, W, dtype=torch.int32, device=dev)}
 
     # the finished image lands in page-locked host memory on rank 0
     if rank == 0:
-        host_img = torch.empty(H, W, 3, dtype=torch.float64, pin_memory=True)
-        host_heat = torch.empty(H, W, 3, dtype=torch.float64, pin_memory=True)
+        host_planes = torch.empty(2, H, W, 3, dtype=torch.float64, pin_memory=True)
 
     def step():
         _, st = res.render(cfg, device_out=out)
-        full = parallel.gather_rows(out["pixels"], H, rank, world)
-        heat = parallel.gather_rows(out["sample_pixels"], H, rank, world)
+        full = parallel.gather_rows(planes, H, rank, world, row_block=row_block, row_dim=1)
         if rank == 0:
-            host_img.copy_(full, non_blocking=True)  # final f64 image on the rank-0 host
-            host_heat.copy_(heat, non_blocking=True)
+            host_planes.copy_(full, non_blocking=True)  # final f64 image + heat-map on the rank-0 host
         # every rank waits for its part of the exchange: the next render reuses the buffers it reads
         torch.cuda.current_stream().synchronize()
-        if rank == 0:
-            return st, host_img, host_heat
-        return st, None, None
+        return st
 
     def sync():
         if world > 1:
@@ -128,8 +229,8 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:  # set up the gather's connections outside the timed region even with --warmup 0
-        out["pixels"].zero_()
-        parallel.gather_rows(out["pixels"], H, rank, world)
+        planes.zero_()
+        parallel.gather_rows(planes, H, rank, world, row_block=row_block, row_dim=1)
     for _ in range(args.warmup):
         step()
     sync()
@@ -138,7 +239,7 @@ def main():
     ms_by_depth = [0.0] * 16
     samples = 0
     for _ in range(args.steps):
-        st, img, heat = step()
+        st = step()
         rays += st.rays
         trace_ms += st.trace_kernel_ms
         launches += st.trace_launches
@@ -149,6 +250,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     rays_by_depth = [int(x) for x in st.rays_by_depth]
+    rays_traced = float(st.rays_traced) * args.steps
 
     tot = torch.tensor([elapsed, rays, trace_ms, launches, float(samples)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -161,22 +263,27 @@ def main():
         trace_ms_max = trace_ms
     rays_all, launches_all, samples_all = float(tot[1]), float(tot[3]), float(tot[4])
 
-    # ---- untimed instrumented render: device-side visit counts for the byte model
+    # ---- untimed instrumented render: device-side visit counts for the byte model and the lane utilisation
     cfg_cnt = cfg.copy()
     cfg_cnt.flags = abi.RT_FLAG_COUNT_VISITS | opt_flags
-    _, st_cnt = res.render(cfg_cnt, device_out=out)
+    if args.profile_pass:
+        st_cnt = abi.RtStats()
+    else:
+        _, st_cnt = res.render(cfg_cnt, device_out=out)
     v_int_dev = st_cnt.node_visits / max(st_cnt.rays_traced, 1)
     v_leaf_dev = st_cnt.leaf_tests / max(st_cnt.rays_traced, 1)
     # fraction of the 64 lanes doing useful work when a wave executes a node step / a leaf test
     lanes_node = st_cnt.node_visits / max(64 * st_cnt.wave_node_steps, 1)
     lanes_leaf = st_cnt.leaf_tests / max(64 * st_cnt.wave_leaf_steps, 1)
+    lanes_useful = (st_cnt.node_visits + st_cnt.leaf_tests) / max(64 * (st_cnt.wave_node_steps + st_cnt.wave_leaf_steps), 1)
 
     # ---- CPU baseline: the oracle (a port of the reference's Rayon path) on a bounded row sample
     cpu = None
     v_int, v_leaf = v_int_dev, v_leaf_dev
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
-        threads = min(16, os.cpu_count() or 1)
+        hc = host_cpu()
+        threads = hc["threads_used"]
         ref_cfg = ri.config.copy()
         ref_cfg.rng_mode = abi.RT_RNG_REF
         probe = ref_cfg.copy()
@@ -198,9 +305,11 @@ def main():
             "unit": "Mrays/s",
             "cores": threads,
             "kind": "port",
+            "host": hc,
             "single_core_value": st_probe.rays / max(st_probe.wall_ms, 1e-6) / 1e3,
             "sample": f"rows {sample.row_first}::{stride} of the same {W}x{H} workload ({cpu_rows} rows, "
-                      f"{int(st_cpu.rays)} rays, {st_cpu.wall_ms / 1e3:.1f} s, reference RNG mode)",
+                      f"{int(st_cpu.rays)} rays, {st_cpu.wall_ms / 1e3:.1f} s, reference RNG mode, {threads} threads = every core "
+                      f"this process may use)",
             "rays": int(st_cpu.rays),
             "seconds": st_cpu.wall_ms / 1e3,
             "time_to_image_s_extrapolated": st_cpu.wall_ms / 1e3 * H / cpu_rows,
@@ -210,18 +319,61 @@ def main():
 
     if rank == 0:
         bytes_per_ray = v_int * NODE_BYTES + v_leaf * TRI_BYTES + RAY_STATE_BYTES
-        # per-GPU figures for the dominant kernel (k_extend): this rank's rays over this rank's kernel time
-        achieved = (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         value = rays_all / elapsed / 1e6
-        traffic = traffic_note = None
         headline = (args.triangles, W, H, args.batch, args.max_batches, args.min_batches) == (100_000, 1200, 1200, 20, 100, 2)
-        if os.path.exists(TRAFFIC_JSON) and headline and not opt_flags:
-            with open(TRAFFIC_JSON) as fh:
-                tj = json.load(fh)
-            if tj.get("hbm_bytes_per_ray"):
-                traffic = tj["hbm_bytes_per_ray"] * rays / max(launches, 1)  # bytes per launch
-                traffic_note = (f"{tj['hbm_bytes_per_ray']:.1f} B/ray from PMC passes (profiles/r01_traffic.json) "
-                                f"x {rays / max(launches, 1):.0f} rays per launch")
+        working_set = sc.n_nodes // 2 * 32 + sc.n_triangles * (80 + 32)  # grid nodes + triangle test and shade records
+        counters = None
+        if os.path.exists(ROOFLINE_INPUTS) and headline and not opt_flags:
+            with open(ROOFLINE_INPUTS) as fh:
+                counters = counter_roofline(json.load(fh), rays_traced, trace_ms, shade_ms, lanes_useful)
+        ext = (counters or {}).get("k_extend")
+        roofline = {
+            "kernel": "k_extend",
+            "launches": launches / args.steps,
+            "avg_launch_ms": trace_ms / max(launches, 1),
+            "kernel_ms_per_step": trace_ms / args.steps,
+            "shade_kernel_ms_per_step": shade_ms / args.steps,
+            "other_kernels_ms_per_step": other_ms / args.steps,
+            "kernel_ms_by_depth_per_step": [x / args.steps for x in ms_by_depth[:cfg.max_depth]],
+            "max_rank_kernel_ms_per_step": trace_ms_max / args.steps,
+            "algorithmic_bytes_per_ray": bytes_per_ray,
+            "algorithmic_bytes_per_launch": rays * bytes_per_ray / max(launches, 1),
+            "algorithmic_GBs": (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
+            "working_set_bytes": working_set,
+            "node_visits_per_ray": v_int, "leaf_tests_per_ray": v_leaf,
+            "node_visits_per_ray_device": v_int_dev, "leaf_tests_per_ray_device": v_leaf_dev,
+            "simd_lane_utilisation": {"node_steps": lanes_node, "leaf_tests": lanes_leaf, "all_steps": lanes_useful},
+        }
+        if working_set < (256 << 20) and ext:
+            # the BVH lives in L2 / Infinity Cache: the kernel is bound by VALU issue on divergent lanes, not by HBM
+            roofline.update({
+                "bound": "valu-issue",
+                "achieved": 100.0 * ext["valu_issue_frac"], "peak": 100.0, "unit": "% of VALU issue cycles spent on useful lanes",
+                "frac": ext["valu_issue_frac"],
+                "valu_busy": ext["valu_busy"], "useful_lane_share": ext["useful_lane_share"],
+                "wait_share_of_wave_time": ext["wait_share_of_wave_time"],
+                "hbm_frac": ext["hbm_frac"], "hbm_GBs": ext["fabric_GBs"], "l2_frac": ext["l2_frac"], "l2_GBs": ext["l2_GBs"],
+                "l2_hit_rate": ext["l2_hit_rate"],
+                "traffic": ext["fabric_bytes"] / max(launches, 1), "traffic_unit": "bytes per launch",
+                "traffic_source": "FETCH_SIZE x fetch_factor + WRITE_SIZE of profiles/roofline_inputs.json (separate --pmc passes), scaled by rays traced",
+                "profiled_avg_launch_ms": ext["profiled_avg_launch_ms"],
+            })
+        elif ext:
+            roofline.update({
+                "bound": "hbm", "achieved": ext["fabric_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext["hbm_frac"],
+                "traffic": ext["fabric_bytes"] / max(launches, 1), "traffic_unit": "bytes per launch",
+            })
+        else:
+            # no counter sums for this workload: only the byte model, which is NOT a fraction of the HBM roof when the
+            # working set is cache resident
+            roofline.update({"bound": "hbm" if working_set >= (256 << 20) else "valu-issue", "achieved": None, "peak": None,
+                             "unit": None, "frac": None, "traffic": None,
+                             "note": "no counter sums for this workload (profiles/roofline_inputs.json covers the headline configuration)"})
+        if counters and "k_shade" in counters:
+            s = counters["k_shade"]
+            roofline["second_kernel"] = {"kernel": "k_shade", "bound": "hbm", "achieved": s["fabric_GBs"], "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": s["hbm_frac"], "valu_busy": s["valu_busy"], "l2_hit_rate": s["l2_hit_rate"],
+                                         "kernel_ms_per_step": shade_ms / args.steps}
         line = {
             "metric": "Mrays/s",
             "value": value,
@@ -241,40 +393,18 @@ def main():
                             f"(attractor), {W}x{H}, batch {cfg.sample_batch_size} x <= {cfg.max_sample_batches} batches "
                             f"(min {cfg.min_sample_batches}), depth {cfg.max_depth}, SAH BVH, adaptive z-test",
                 "elements": sc.n_elements, "bvh_nodes": sc.n_nodes, "bvh_depth": ri.bvh_depth(),
-                "rows_per_rank": n_rows, "parallelism": f"rows interleaved over {world} GPU(s), gather to rank 0",
+                "rows_per_rank": n_rows, "row_block": row_block,
+                "parallelism": f"blocks of {row_block} row(s) dealt over {world} GPU(s), one gather to rank 0",
                 "early_terminate": bool(args.early_terminate), "reference_visit_rule": bool(args.reference_visits),
             },
             "rays_per_step": rays_all / args.steps,
+            "rays_traced_per_step_rank0": rays_traced / args.steps,
             "mean_spp": samples_all / args.steps / (W * H),
             "rays_by_depth_rank0_last_step": rays_by_depth[:cfg.max_depth],
             "host_build_s": t_host,
             "upload_s": t_upload,
             "time_to_image_with_load_build_upload_s": elapsed / args.steps + t_host + t_upload,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_extend",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_note,
-                "algorithmic_bytes_per_launch": rays * bytes_per_ray / max(launches, 1),
-                "bytes_per_ray": bytes_per_ray,
-                "node_visits_per_ray": v_int,
-                "leaf_tests_per_ray": v_leaf,
-                "node_visits_per_ray_device": v_int_dev,
-                "leaf_tests_per_ray_device": v_leaf_dev,
-                "simd_lane_utilisation": {"node_steps": lanes_node, "leaf_tests": lanes_leaf},
-                "launches": launches / args.steps,
-                "avg_launch_ms": trace_ms / max(launches, 1),
-                "kernel_ms_per_step": trace_ms / args.steps,
-                "shade_kernel_ms_per_step": shade_ms / args.steps,
-                "other_kernels_ms_per_step": other_ms / args.steps,
-                "kernel_ms_by_depth_per_step": [x / args.steps for x in ms_by_depth[:cfg.max_depth]],
-                "max_rank_kernel_ms_per_step": trace_ms_max / args.steps,
-            },
+            "roofline": roofline,
             "cpu_baseline": cpu,
             "rust_sys_crate": rust_crate_check(),
         }

@@ -192,11 +192,16 @@ typedef struct RtConfig {
   int32_t rng_mode; /* RT_RNG_REF | RT_RNG_CTR */
   int32_t flags;    /* RT_FLAG_* bits, 0 for the reference's behaviour */
   uint64_t seed; /* extra key for RT_RNG_CTR; ignored by RT_RNG_REF */
-  /* Row shard: this call renders image rows y = row_first + k*row_stride
-   * (k = 0,1,...) with y < img_height.  (0,1) is the whole image.  Output
-   * buffers hold only those rows, k-th owned row at offset k*img_width. */
+  /* Row shard.  The image is cut into blocks of row_block consecutive rows
+   * (0 or 1: single rows) and this call renders the blocks
+   * b = row_first + j*row_stride (j = 0,1,...) with b*row_block < img_height;
+   * (0,1) is the whole image.  Output buffers hold only those rows: the k-th
+   * row of the shard, at offset k*img_width, is image row
+   *   (row_first + (k / row_block) * row_stride) * row_block + k % row_block. */
   int32_t row_first;
   int32_t row_stride;
+  int32_t row_block;
+  int32_t reserved;
 } RtConfig;
 
 /* Output buffers, caller-allocated, library-filled.  n_rows = number of rows

@@ -84,15 +84,20 @@ def primary_hits_threads(scene_ptr, cfg, n_threads=8):
     prim = np.empty(shape, dtype=np.int32)
     t = np.empty(shape, dtype=np.float64)
 
+    b = max(1, cfg.row_block)
+    n_blocks = (n_rows + b - 1) // b  # blocks of the shard; thread k takes the shard's blocks k, k + n_threads, ...
+
     def part(k):
         c = cfg.copy()
         c.row_first = cfg.row_first + k * cfg.row_stride
         c.row_stride = cfg.row_stride * n_threads
-        return k, primary_hits(scene_ptr, c)
+        mine = [r for j in range(k, n_blocks, n_threads) for r in range(j * b, min((j + 1) * b, n_rows))]
+        return mine, (primary_hits(scene_ptr, c) if mine else (None, None))
 
     with ThreadPoolExecutor(n_threads) as pool:
-        for k, (p, tt) in pool.map(part, range(n_threads)):
-            prim[k::n_threads], t[k::n_threads] = p, tt
+        for mine, (p, tt) in pool.map(part, range(n_threads)):
+            if mine:
+                prim[mine], t[mine] = p, tt
     return prim, t
 
 

@@ -758,6 +758,22 @@ static void render_line(const RtScene *sc, const RtConfig *cfg, int y, double *b
   free(stats.weights);
 }
 
+/* The row shard of RtConfig: blocks of row_block rows (0 or 1: single rows), the blocks row_first,
+ * row_first + row_stride, ... of the image. */
+static int row_block_of(const RtConfig *cfg) { return cfg->row_block > 1 ? cfg->row_block : 1; }
+static int shard_rows(const RtConfig *cfg) {
+  int B = row_block_of(cfg), n_blocks = (cfg->img_height + B - 1) / B;
+  if (cfg->row_stride <= 0 || cfg->row_first < 0 || cfg->row_first >= n_blocks) return 0;
+  int mine = (n_blocks - cfg->row_first + cfg->row_stride - 1) / cfg->row_stride;
+  int rows = mine * B;
+  if (cfg->row_first + (mine - 1) * cfg->row_stride == n_blocks - 1 && cfg->img_height % B) rows -= B - cfg->img_height % B;
+  return rows;
+}
+static int image_row(const RtConfig *cfg, int k) {
+  int B = row_block_of(cfg);
+  return (cfg->row_first + (k / B) * cfg->row_stride) * B + k % B;
+}
+
 /* ============================ driver: rows fan out over a thread pool,
  * mirroring the Rayon par_iter of integrator.rs:226-243 (one task = one row,
  * dynamic hand-out). */
@@ -779,7 +795,7 @@ static void *worker(void *arg) {
   for (;;) {
     int k = __sync_fetch_and_add(&job->next_row, 1);
     if (k >= job->n_rows) break;
-    int y = job->cfg->row_first + k * job->cfg->row_stride;
+    int y = image_row(job->cfg, k);
     size_t off = (size_t)k * (size_t)width;
     render_line(job->sc, job->cfg, y, job->out->pixels + 3 * off,
                 job->out->sample_pixels ? job->out->sample_pixels + 3 * off : NULL,
@@ -794,11 +810,6 @@ static void *worker(void *arg) {
   for (int i = 0; i < RT_MAX_DEPTH_STATS; i++) job->total.rays_by_depth[i] += cn.rays_by_depth[i];
   pthread_mutex_unlock(&job->mu);
   return NULL;
-}
-
-static int shard_rows(const RtConfig *cfg) {
-  if (cfg->row_stride <= 0 || cfg->row_first < 0 || cfg->row_first >= cfg->img_height) return 0;
-  return (cfg->img_height - cfg->row_first + cfg->row_stride - 1) / cfg->row_stride;
 }
 
 static double now_ms(void) {
@@ -849,7 +860,7 @@ int rt_oracle_primary_hits(const RtScene *sc, const RtConfig *cfg, int32_t *prim
   counters_t cn;
   memset(&cn, 0, sizeof cn);
   for (int k = 0; k < n_rows; k++) {
-    int y = cfg->row_first + k * cfg->row_stride;
+    int y = image_row(cfg, k);
     rng_t rng;
     rng_seed_from_u64(&rng, (uint64_t)y);
     for (int x = 0; x < cfg->img_width; x++) {

@@ -100,6 +100,7 @@ class RtConfig(C.Structure):
         ("rng_mode", C.c_int32), ("flags", C.c_int32),
         ("seed", C.c_uint64),
         ("row_first", C.c_int32), ("row_stride", C.c_int32),
+        ("row_block", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def copy(self):
@@ -107,8 +108,22 @@ class RtConfig(C.Structure):
         C.memmove(C.byref(c), C.byref(self), C.sizeof(RtConfig))
         return c
 
+    def rows(self):
+        """Image rows of the shard, in the order the output buffers hold them."""
+        b = max(1, self.row_block)
+        n_blocks = (self.img_height + b - 1) // b
+        return [y for blk in range(self.row_first, n_blocks, self.row_stride) for y in range(blk * b, min((blk + 1) * b, self.img_height))]
+
     def n_rows(self):
-        return (self.img_height - self.row_first + self.row_stride - 1) // self.row_stride
+        b = max(1, self.row_block)
+        n_blocks = (self.img_height + b - 1) // b
+        if self.row_first >= n_blocks:
+            return 0
+        mine = (n_blocks - self.row_first + self.row_stride - 1) // self.row_stride
+        rows = mine * b
+        if self.row_first + (mine - 1) * self.row_stride == n_blocks - 1 and self.img_height % b:
+            rows -= b - self.img_height % b
+        return rows
 
 
 class RtImage(C.Structure):

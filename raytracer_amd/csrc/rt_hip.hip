@@ -109,7 +109,7 @@ struct HitBuffer {
 };
 
 struct RenderParams {
-  int32_t width, height, row_first, row_stride;
+  int32_t width, height, row_first, row_stride, row_block;
   int32_t S;  // sample_batch_size
   int32_t max_batches, min_batches, max_depth;
   double pixel_radius, gamma, filter_b, filter_c;
@@ -131,6 +131,11 @@ struct RenderParams {
 // fixed set of k_shade workgroups -- is a fair sample of the image: cheap and costly parts of
 // the picture do not pile up in different regions.
 constexpr uint32_t kTileLog = RT_TILE_LOG;  // log2 of the side of a square tile; a tile has 4^kTileLog pixels
+// image row of row `k` of the shard (RtConfig.row_first / row_stride / row_block)
+__device__ __forceinline__ int32_t image_row(const RenderParams &rp, uint32_t k) {
+  uint32_t blk = k / (uint32_t)rp.row_block;
+  return (rp.row_first + (int32_t)blk * rp.row_stride) * rp.row_block + (int32_t)(k - blk * (uint32_t)rp.row_block);
+}
 __device__ __forceinline__ uint32_t pixel_of_key(const RenderParams &rp, uint32_t key) {
   uint32_t within = key & ((1u << (2 * kTileLog)) - 1u), rank = key >> (2 * kTileLog);
   uint32_t tile = (uint32_t)(((uint64_t)rank * rp.tile_inv) % rp.n_tiles);
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
     int32_t slot = (int32_t)(sg / (uint32_t)G), g = (int32_t)(sg - (uint32_t)slot * (uint32_t)G);
     uint32_t p = pixel_of_key(rp, active[slot]);
     int32_t x = (int32_t)(p % (uint32_t)rp.width);
-    int32_t y = rp.row_first + (int32_t)(p / (uint32_t)rp.width) * rp.row_stride;
+    int32_t y = image_row(rp, p / (uint32_t)rp.width);
     // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
     uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
     double sx = ((double)sobol_sample((uint32_t)i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
@@ -964,7 +969,7 @@ __global__ void __launch_bounds__(256) k_primary_rays(DevScene sc, RenderParams 
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     int32_t p = (int32_t)(j / rp.S), i = (int32_t)(j % rp.S);
     int32_t x = p % rp.width;
-    int32_t y = rp.row_first + (p / rp.width) * rp.row_stride;
+    int32_t y = image_row(rp, (uint32_t)(p / rp.width));
     uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
     double sx = ((double)sobol_sample((uint32_t)i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
     double sy = ((double)sobol_sample((uint32_t)i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
@@ -1135,8 +1140,15 @@ float round_up(double x) {
   return f;
 }
 
-int shard_rows(const RtConfig *cfg) {
-  return (cfg->img_height - cfg->row_first + cfg->row_stride - 1) / cfg->row_stride;
+int row_block_of(const RtConfig *cfg) { return cfg->row_block > 1 ? cfg->row_block : 1; }
+int shard_rows(const RtConfig *cfg) {  // rows in the blocks row_first, row_first + row_stride, ... of the image
+  const int B = row_block_of(cfg), n_blocks = (cfg->img_height + B - 1) / B;
+  if (cfg->row_first >= n_blocks) return 0;
+  const int mine = (n_blocks - cfg->row_first + cfg->row_stride - 1) / cfg->row_stride;
+  int rows = mine * B;
+  // only the image's last block can be short, and if the shard owns it, it is the shard's last too
+  if (cfg->row_first + (mine - 1) * cfg->row_stride == n_blocks - 1 && cfg->img_height % B) rows -= B - cfg->img_height % B;
+  return rows;
 }
 
 int check_config(const RtConfig *cfg) {
@@ -1144,7 +1156,7 @@ int check_config(const RtConfig *cfg) {
   if (cfg->img_width <= 0 || cfg->img_height <= 0) return fail(RT_ERR_BAD_ARG, "image size must be positive");
   if (cfg->sample_batch_size <= 0 || cfg->max_sample_batches <= 0 || cfg->min_sample_batches < 0 || cfg->max_depth < 0)
     return fail(RT_ERR_BAD_ARG, "sample_batch_size and max_sample_batches must be >= 1; min_sample_batches, max_depth >= 0");
-  if (cfg->row_stride <= 0 || cfg->row_first < 0 || cfg->row_first >= cfg->img_height)
+  if (cfg->row_stride <= 0 || cfg->row_first < 0 || cfg->row_block < 0 || (int64_t)cfg->row_first * row_block_of(cfg) >= cfg->img_height)
     return fail(RT_ERR_BAD_ARG, "row shard out of range");
   if (!(cfg->pixel_radius > 0.0) || !(cfg->gamma_correction > 0.0)) return fail(RT_ERR_BAD_ARG, "pixel_radius and gamma_correction must be > 0");
   if (cfg->rng_mode != RT_RNG_CTR)
@@ -1160,6 +1172,7 @@ RenderParams make_params(const RtConfig *cfg) {
   rp.height = cfg->img_height;
   rp.row_first = cfg->row_first;
   rp.row_stride = cfg->row_stride;
+  rp.row_block = row_block_of(cfg);
   rp.S = cfg->sample_batch_size;
   rp.max_batches = cfg->max_sample_batches;
   rp.min_batches = cfg->min_sample_batches;
@@ -1172,9 +1185,18 @@ RenderParams make_params(const RtConfig *cfg) {
   rp.n_pix = shard_rows(cfg) * cfg->img_width;
   rp.flags = cfg->flags;
   // tile order of the active list: a multiplier near 0.618 * n_tiles, coprime to n_tiles, and its inverse
-  // rows of the shard are row_stride image rows apart: trade tile height for width accordingly
+  // Rows of the shard are neighbours in the image only inside a block of row_block rows, and blocks are
+  // row_stride blocks apart: a tile is as high as the largest power of two that divides the block (at most
+  // 2^kTileLog; single rows: trade tile height for width by the stride) and correspondingly wider.
   rp.tile_hlog = kTileLog;
-  for (int s = cfg->row_stride; s > 1 && rp.tile_hlog > 0; s >>= 1) rp.tile_hlog--;
+  if (cfg->row_stride > 1) {
+    if (rp.row_block > 1) {
+      rp.tile_hlog = 0;
+      while (rp.tile_hlog < kTileLog && rp.row_block % (2 << rp.tile_hlog) == 0) rp.tile_hlog++;
+    } else {
+      for (int s = cfg->row_stride; s > 1 && rp.tile_hlog > 0; s >>= 1) rp.tile_hlog--;
+    }
+  }
   if (const char *env = getenv("RT_HIP_TILE_HLOG")) rp.tile_hlog = (uint32_t)std::min<int>(2 * (int)kTileLog, std::max(0, atoi(env)));
   rp.tile_wlog = 2 * kTileLog - rp.tile_hlog;
   rp.tiles_x = ((uint32_t)cfg->img_width + (1u << rp.tile_wlog) - 1u) >> rp.tile_wlog;

@@ -12,57 +12,68 @@ final gather (RCCL over xGMI when the backend is "nccl"; gloo on CPU).
 import numpy as np
 
 
-def shard_rows(height, rank, world):
-    """Row indices owned by `rank`."""
-    return list(range(rank, height, world))
+ROW_BLOCK = 1  # rows dealt together; see shard_config
 
 
-def shard_config(cfg, rank, world):
+def shard_rows(height, rank, world, row_block=ROW_BLOCK):
+    """Image rows owned by `rank`, in the order its buffers hold them: the blocks rank, rank + world, ...
+    of `row_block` consecutive rows each."""
+    b = max(1, row_block)
+    n_blocks = (height + b - 1) // b
+    return [y for blk in range(rank, n_blocks, world) for y in range(blk * b, min((blk + 1) * b, height))]
+
+
+def shard_config(cfg, rank, world, row_block=ROW_BLOCK):
+    """The configuration of `rank`'s shard: blocks of `row_block` rows dealt round-robin (RtConfig.row_first /
+    row_stride / row_block).  A single process renders the whole image whatever the block size."""
     c = cfg.copy()
     c.row_first = rank
     c.row_stride = world
+    c.row_block = max(1, row_block) if world > 1 else 0
     return c
 
 
-def max_rows(height, world):
-    return (height + world - 1) // world
+def max_rows(height, world, row_block=ROW_BLOCK):
+    return max(len(shard_rows(height, r, world, row_block)) for r in range(world))
 
 
-def gather_rows(local, height, rank, world, dst=0):
-    """Gather per-rank row blocks [rows_r, W, C] into the full [H, W, C] image on `dst`.
+def gather_rows(local, height, rank, world, dst=0, row_block=ROW_BLOCK, row_dim=0):
+    """Gather per-rank shards into the full image on `dst` with ONE collective.
 
-    `local` is a torch tensor (CUDA for nccl, CPU for gloo).  Ranks may own
-    different row counts when world does not divide height; blocks are padded to
-    the largest count for the collective.  Returns the assembled tensor on
-    `dst`, None elsewhere.
+    `local` is a torch tensor (CUDA for nccl, CPU for gloo) whose dimension `row_dim` runs over the
+    rank's rows (shard_rows order); other leading dimensions may stack several planes (image and
+    heat-map) so that they travel together.  Ranks may own different row counts; shards are padded
+    to the largest for the collective.  Returns the assembled tensor on `dst`, None elsewhere.
     """
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return local
-    mr = max_rows(height, world)
-    pad = local
-    if local.shape[0] < mr:
-        pad = torch.zeros((mr,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-    pad = pad.contiguous()
+    rows_first = local.movedim(row_dim, 0)
+    mr = max_rows(height, world, row_block)
+    if rows_first.shape[0] < mr or not rows_first.is_contiguous():
+        pad = torch.zeros((mr,) + tuple(rows_first.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: rows_first.shape[0]] = rows_first
+    else:
+        pad = rows_first
     if rank == dst:
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.gather(pad, gather_list=parts, dst=dst)
-        full = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        full = torch.empty((height,) + tuple(pad.shape[1:]), dtype=local.dtype, device=local.device)
         for r in range(world):
-            n = len(range(r, height, world))
-            full[r::world] = parts[r][:n]
-        return full
+            rows = shard_rows(height, r, world, row_block)
+            full[torch.as_tensor(rows, device=local.device)] = parts[r][: len(rows)]
+        return full.movedim(0, row_dim)
     dist.gather(pad, gather_list=None, dst=dst)
     return None
 
 
-def interleave_numpy(parts, height):
-    """CPU equivalent of the de-interleave step: parts[r] holds rows r::len(parts)."""
+def interleave_numpy(parts, height, row_block=ROW_BLOCK):
+    """CPU equivalent of the de-interleave step: parts[r] holds the rows shard_rows(height, r, len(parts))."""
     world = len(parts)
     full = np.empty((height,) + parts[0].shape[1:], dtype=parts[0].dtype)
     for r in range(world):
-        full[r::world] = parts[r][: len(range(r, height, world))]
+        rows = shard_rows(height, r, world, row_block)
+        full[rows] = parts[r][: len(rows)]
     return full
