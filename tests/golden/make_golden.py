@@ -8,7 +8,7 @@ oracle's behaviour (so an accidental change to it is caught on CPU) and give the
 GPU tests fixed vectors that do not depend on running the oracle.  They are not
 outputs of the reference.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [c3]      ("c3": only the headline-workload rows, the slow part)
 """
 import os
 import sys
@@ -24,7 +24,16 @@ from raytracer_amd import abi  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 
+C3_REF_ROWS = (11, 38)  # rows 11, 49, ..., 1189
+
+
 def main():
+    if "c3" not in sys.argv[1:]:
+        small()
+    headline()
+
+
+def small():
     # 1. primary-hit map of the C1 scene, 32x32, 4 samples per pixel
     ri = c1(width=32, height=32, batch=4)
     cfg = ri.config.copy()
@@ -54,6 +63,21 @@ def main():
     ctr_u = np.array(oracle.rng_stream(abi.RT_RNG_CTR, 42, 0, 16), dtype=np.uint64)
     rng_f = np.array(oracle.rng_stream(abi.RT_RNG_REF, 42, 1, 16, lo=0.0, hi=1.0))
     np.savez_compressed(os.path.join(HERE, "samplers.npz"), sobol=sob, xoshiro_seed42=xo, counter_pixel42=ctr_u, gen_range_seed42=rng_f)
+
+
+def headline():
+    # 5. the headline workload in the reference's own random-number mode: 32 evenly spaced rows of the
+    #    1200x1200 README-like scene (100 000-triangle mesh, batches of 20, up to 100, z-test), one
+    #    xoshiro256++ per row as integrator.rs:263.  The statistical gate of the GPU tests compares against it.
+    from raytracer_amd import RenderIntegrator, scenes  # noqa: E402
+    scene_path, config_path = scenes.materialize_c3(os.path.join(HERE, "_tmp"))
+    ri = RenderIntegrator.new_from_json(scene_path, config_path).prepare()
+    rows = ri.config.copy()
+    rows.rng_mode = abi.RT_RNG_REF
+    rows.row_first, rows.row_stride = C3_REF_ROWS
+    out, st = oracle.render(ri.scene, rows, os.cpu_count() or 4)
+    np.savez_compressed(os.path.join(HERE, "c3_ref_rows.npz"), linear=out["linear"].astype(np.float32), samples=out["samples"].astype(np.uint16),
+                        row_first=np.int32(rows.row_first), row_stride=np.int32(rows.row_stride), rays=np.int64(st.rays))
     import shutil
     shutil.rmtree(os.path.join(HERE, "_tmp"), ignore_errors=True)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

@@ -89,3 +89,30 @@ def test_full_size_rows_match_the_oracle(full):
     g = {k: out[k][250::400] for k in ("linear", "samples", "sample_pixels")}
     assert_image_parity(g, o, "C3 rows 250, 650, 1050", res, rows)
     assert abs(int(so.rays) - int(st.rays) * 3 // 1200) < 0.2 * so.rays
+
+
+def test_full_size_agrees_with_the_reference_rng_mode_within_noise(full):
+    """The north star's third gate at the configuration the metric is quoted on: against the oracle in the
+    reference's own random-number mode (one xoshiro256++ per image row, integrator.rs:263 -- a different sample
+    sequence, so only statistics can agree) on 32 evenly spaced rows of the image (tests/golden/c3_ref_rows.npz,
+    written by tests/golden/make_golden.py).  Bound: the device's image may differ from the reference-mode image
+    by no more than 1.05 x what two device renders with different seeds differ by (pure Monte-Carlo noise at the
+    same sample counts); mean radiance within 1e-3 relative; mean samples per pixel within 0.25 % (every pixel's
+    stopping batch is a random variable of its sample sequence: over these 38 400 pixels the two modes differ by
+    0.11 %, over the whole image by 0.002 %)."""
+    from helpers import GOLDEN, noise_gate
+    ri, res, cfg, out, st = full
+    g = np.load(os.path.join(GOLDEN, "c3_ref_rows.npz"))
+    first, stride = int(g["row_first"]), int(g["row_stride"])
+    ref_linear, ref_samples = g["linear"].astype(np.float64), g["samples"].astype(np.int64)
+    a = out["linear"][first::stride]
+    assert a.shape == ref_linear.shape == (32, 1200, 3)
+    other = cfg.copy()
+    other.row_first, other.row_stride, other.seed = first, stride, 20261111
+    b, _ = res.render(other)
+    rmse_ref, rmse_self = noise_gate(a, b["linear"], ref_linear, 1.05)
+    assert rmse_self > 1e-4                                   # the comparison is between noisy estimates, not zeros
+    for c in range(3):
+        assert abs(a[..., c].mean() - ref_linear[..., c].mean()) <= 1e-3 * ref_linear[..., c].mean(), c
+    spp, spp_ref = out["samples"][first::stride].mean(), ref_samples.mean()
+    assert abs(spp - spp_ref) <= 2.5e-3 * spp_ref, (spp, spp_ref)
