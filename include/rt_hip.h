@@ -295,6 +295,26 @@ int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *pri
 int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins,
                       const double *directions, int32_t *prim_id, double *t);
 
+/* Opt-in: build the BVH on the device instead of uploading the host's.  Where
+ * the reference builds its tree in BVH_SAH::build (bvh_node_sah.rs:147-159,
+ * 256-461: Mid or 16-bucket SAH, one host thread) this entry point takes the
+ * primitives alone (scene->nodes and n_nodes are ignored) and builds a linear
+ * BVH over Morton codes on the GPU; everything else is as after
+ * rt_hip_scene_upload.  Differences a caller must accept:
+ *   - boxes are the primitives' true bounds (the reference boxes a quad by two
+ *     corners only, quad.rs:86, and can lose hits on a tilted quad's
+ *     overhang; this tree finds them);
+ *   - primitives hit at exactly the same t are told apart by THIS tree's
+ *     depth-first leaf order, not the reference tree's.
+ * Hit distances are those of the reference's primitive tests either way. */
+int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
+
+/* Debug / test aid: the tree a handle holds, as RtNode records (2*k+1 nodes
+ * for k internal nodes: the root first, every leaf after the internal nodes;
+ * child boxes are the f32 boxes the device tests).  With nodes == NULL only
+ * *n_nodes is written.  Works for uploaded and device-built scenes. */
+int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t capacity, int32_t *n_nodes);
+
 /* The queries of rt_hip_trace_rays for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  It has no counterpart in the reference.  The call makes

@@ -158,7 +158,7 @@ class RtStats(C.Structure):
 HIP_SYMBOLS = [
     "rt_hip_last_error", "rt_hip_device_count", "rt_hip_scene_upload", "rt_hip_scene_free",
     "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays", "rt_hip_set_progress",
-    "rt_hip_trace_rays_noalloc",
+    "rt_hip_trace_rays_noalloc", "rt_hip_scene_build", "rt_hip_scene_download_tree",
 ]
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
@@ -194,6 +194,8 @@ def hip_lib():
         lib.rt_hip_primary_hits.argtypes = [C.c_void_p, C.POINTER(RtConfig), C.c_void_p, C.c_void_p]
         lib.rt_hip_trace_rays.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_hip_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_hip_scene_build.argtypes = [C.POINTER(RtScene), C.c_int, C.POINTER(C.c_void_p)]
+        lib.rt_hip_scene_download_tree.argtypes = [C.c_void_p, C.POINTER(RtNode), C.c_int32, C.POINTER(C.c_int32)]
         lib.rt_hip_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _hip = lib
     return _hip

@@ -31,6 +31,11 @@ constexpr uint32_t kRefIndexMask = 0x0fffffffu;
 constexpr uint32_t kRefNone = 0xffffffffu;
 constexpr int kRefKindShift = 29;
 constexpr int kMaxStackDepth = 64;
+constexpr int kLdsStackLevels = 24;  // stack entries per lane held in LDS by the order-free walk once it spills
+constexpr int kSpillAboveDepth = 27; // trees up to this height keep the whole stack in LDS: (27 + 4 leaf-queue levels) x 256 B
+                                     // per wave still lets 20 waves (the register limit) share a CU's 160 KB; measured on a
+                                     // 2 M-triangle scene: height 26 all in LDS 1243 ms, spilling above 24 levels 1315 ms;
+                                     // height 38 all in LDS 1649 ms, 28 levels in LDS 1478 ms, 24 levels 1396 ms
 
 // 64-byte internal node: both child boxes (f32, rounded outward) + child refs.
 struct __attribute__((aligned(64))) DevNode {
@@ -98,7 +103,11 @@ struct DevScene {
   int32_t n_attractors;
   int32_t n_materials;
   uint32_t root;        // ref of nodes[0] of the reference array
-  int32_t stack_depth;  // LDS stack entries per lane
+  int32_t stack_depth;  // stack entries a lane can need (the height of the tree)
+  // The order-free walk keeps the first kLdsStackLevels entries of a lane's stack in LDS; a deeper tree (a
+  // linear BVH built on the device is about twice as high as a SAH tree) spills the rest to this buffer,
+  // laid out [level][wave][lane], so that the LDS footprint of a wave does not cost occupancy.
+  uint32_t *stack_spill;
   int32_t quirk;        // 1 when the walk must follow the reference's visit rule step by step: some child box
                         // does not contain the primitives below it, or the nodes do not form a tree
   // When the only offenders are a few primitives that stick out of their own leaf boxes, `danger` holds
@@ -487,6 +496,33 @@ RT_DEV void trav_begin(const DevScene &sc, Traversal &tv) {
   tv.best.ref = kRefNone;
 }
 
+// A lane's stack: LDS for the first levels, global memory beyond (SPILL instantiations only).
+struct StackRef {
+  uint32_t *lds;     // this lane's slot of level 0; levels are 64 entries apart
+  uint32_t *spill;   // this lane's slot of the first spilled level; levels are `spill_stride` entries apart
+  uint32_t spill_stride;
+};
+template <bool SPILL>
+RT_DEV void stack_store(const StackRef &s, int level, uint32_t v) {
+  if (!SPILL || level < kLdsStackLevels) s.lds[level * 64] = v;
+  else s.spill[(size_t)(level - kLdsStackLevels) * s.spill_stride] = v;
+}
+template <bool SPILL>
+RT_DEV uint32_t stack_load(const StackRef &s, int level) {
+  if (!SPILL || level < kLdsStackLevels) return s.lds[level * 64];
+  return s.spill[(size_t)(level - kLdsStackLevels) * s.spill_stride];
+}
+// the order-free walk's pop: entries are children whose box the ray hits
+template <bool SPILL>
+RT_DEV void trav_pop_fast(Traversal &tv, const StackRef &s) {
+  if (tv.sp == 0) {
+    tv.cur = kDone;
+  } else {
+    tv.sp--;
+    tv.cur = stack_load<SPILL>(s, tv.sp);
+  }
+}
+
 // Take the next node off the stack.
 //   !QUIRK: entries are right children whose box the ray hits.
 //   QUIRK : every right child of a node whose left box was hit is on the stack
@@ -527,53 +563,53 @@ RT_DEV void trav_pop(Traversal &tv, const uint32_t *stack, int stride) {
   }
 }
 
-// One internal-node step: fetch the 64-byte node, test both child boxes,
-// descend / push / pop.
-template <bool QUIRK>
-RT_DEV void trav_node(const DevScene &sc, const RayF &f, Traversal &tv, uint32_t *stack, int stride) {
+// One internal-node step of the order-free walk on the 64-byte f32 records: boxes bound their
+// contents, so which leaves are tested, and in which order, cannot change the result
+// (trav_test_leaf breaks ties by the reference's leaf order).  Enter the nearer child first and
+// drop children that begin beyond the closest hit so far.
+template <bool SPILL>
+RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, const StackRef &stack) {
   const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
   float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
   uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
-  if (!QUIRK) {
-    // Boxes bound their contents: which leaves are tested, and in which order, cannot change
-    // the result (trav_test_leaf breaks ties by the reference's leaf order).  Enter the nearer
-    // child first and drop children that begin beyond the closest hit so far.
-    float tl, tr;
-    bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tv.tcull, tl);
-    bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
-    if (hl && hr) {
-      bool swap = tr < tl;
-      stack[tv.sp * stride] = swap ? left : right;
-      tv.sp++;
-      tv.cur = swap ? right : left;
-    } else if (hl || hr) {
-      tv.cur = hl ? left : right;
-    } else {
-      trav_pop<QUIRK>(tv, stack, stride);
-    }
-    return;
+  float tl, tr;
+  bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tv.tcull, tl);
+  bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
+  if (hl && hr) {
+    bool swap = tr < tl;
+    stack_store<SPILL>(stack, tv.sp, swap ? left : right);
+    tv.sp++;
+    tv.cur = swap ? right : left;
+  } else if (hl || hr) {
+    tv.cur = hl ? left : right;
+  } else {
+    trav_pop_fast<SPILL>(tv, stack);
   }
+}
+
+// One internal-node step of the walk that follows the reference's visit rule: fetch the 64-byte
+// node, test both child boxes, descend / push / pop.
+RT_DEV void trav_node_ref(const DevScene &sc, const RayF &f, Traversal &tv, uint32_t *stack, int stride) {
+  const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
+  float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+  uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
   bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f);
   bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f);
   if (hl) {
-    if (QUIRK) {
-      stack[tv.sp * stride] = right | (hr ? kRefFlag : 0u);
-      tv.hitmask &= ~(1ull << tv.sp);
-      tv.sp++;
-    } else if (hr) {
-      stack[tv.sp * stride] = right;
-      tv.sp++;
-    }
+    stack[tv.sp * stride] = right | (hr ? kRefFlag : 0u);
+    tv.hitmask &= ~(1ull << tv.sp);
+    tv.sp++;
     tv.cur = left;
   } else if (hr) {
     tv.cur = right;
   } else {
-    trav_pop<QUIRK>(tv, stack, stride);
+    trav_pop<true>(tv, stack, stride);
   }
 }
 
 // The node step on the 32-byte grid records (order-free walk only).
-RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, uint32_t *stack, int stride) {
+template <bool SPILL>
+RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const StackRef &stack) {
   const uint4 *p = reinterpret_cast<const uint4 *>(&sc.nodes_q[tv.cur & kRefIndexMask]);
   uint4 w0 = p[0], w1 = p[1];
   // halves of the words, in the order of DevNodeQ
@@ -587,14 +623,22 @@ RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, uint32
   bool hr = slab_hit_q(rminx, rminy, rminz, rmaxx, rmaxy, rmaxz, r, tv.tcull, tr);
   if (hl && hr) {
     bool swap = tr < tl;
-    stack[tv.sp * stride] = swap ? left : right;
+    stack_store<SPILL>(stack, tv.sp, swap ? left : right);
     tv.sp++;
     tv.cur = swap ? right : left;
   } else if (hl || hr) {
     tv.cur = hl ? left : right;
   } else {
-    trav_pop<false>(tv, stack, stride);
+    trav_pop_fast<SPILL>(tv, stack);
   }
+}
+
+// Queue the leaf in `cur` for the next leaf phase and move on (order-free walk).
+template <bool SPILL>
+RT_DEV void trav_defer_leaf_fast(Traversal &tv, const StackRef &stack, uint32_t *leafq) {
+  leafq[tv.qn * 64] = tv.cur;
+  tv.qn++;
+  trav_pop_fast<SPILL>(tv, stack);
 }
 
 // Queue the leaf in `cur` for the next leaf phase and move on.

@@ -25,6 +25,7 @@
 // wave touches consecutive addresses.
 #include <hip/hip_runtime.h>
 #include <hipcub/device/device_radix_sort.hpp>
+#include <hipcub/device/device_scan.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -246,14 +247,16 @@ struct ExtendTuning {
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
-template <bool QUIRK, bool COUNT, bool GRID>
+template <bool QUIRK, bool COUNT, bool GRID, bool SPILL>
 __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
                                                 ExtendTuning tune, unsigned long long *visit_counters) {
   const uint32_t lane = threadIdx.x;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int stride = 64;
   uint32_t *stack = g_lds + lane;
-  uint32_t *leafq = g_lds + (size_t)sc.stack_depth * 64 + lane;
+  const int lds_levels = SPILL ? kLdsStackLevels : sc.stack_depth;
+  uint32_t *leafq = g_lds + (size_t)lds_levels * 64 + lane;
+  const StackRef sref = {stack, SPILL ? sc.stack_spill + (size_t)blockIdx.x * 64 + lane : nullptr, gridDim.x * 64u};
   const uint32_t home = blockIdx.x % kRegions;
   const uint32_t waves_per_region = gridDim.x / kRegions;
   uint32_t region_try = 0;         // regions tried so far (wave-uniform)
@@ -332,19 +335,23 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
       if (COUNT) wn++;
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
-        if (GRID) trav_node_q(sc, fq, tv, stack, stride);
-        else trav_node<QUIRK>(sc, f, tv, stack, stride);
+        if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
+        else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
+        else trav_node_fast<SPILL>(sc, f, tv, sref);
       }
-      if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
+      if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) {
+        if (QUIRK) trav_defer_leaf<true>(tv, stack, leafq, stride);
+        else trav_defer_leaf_fast<SPILL>(tv, sref, leafq);
+      }
 #pragma unroll
       for (int extra = 0; extra < (QUIRK ? 0 : RT_EXTRA_STEPS); extra++) {  // more steps before the wave votes again
         if (COUNT) wn++;
         if (!(tv.cur & kRefLeaf)) {
           if (COUNT) nn++;
-          if (GRID) trav_node_q(sc, fq, tv, stack, stride);
-          else trav_node<QUIRK>(sc, f, tv, stack, stride);
+          if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
+          else trav_node_fast<SPILL>(sc, f, tv, sref);
         }
-        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf<QUIRK>(tv, stack, leafq, stride);
+        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SPILL>(tv, sref, leafq);
       }
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
     // ------------------------------------------------------------ leaf phase
@@ -390,7 +397,12 @@ static ExtendTuning extend_tuning() {
   return t;
 }
 
-static size_t extend_lds_bytes(const DevScene &sc) { return (size_t)(sc.stack_depth + kMaxLeafQueue) * 64 * sizeof(uint32_t); }
+// The walk that follows the reference's rule keeps its whole stack in LDS; the order-free walk at most kLdsStackLevels levels.
+static bool extend_spills(const DevScene &sc, bool quirk) { return !quirk && sc.stack_depth > kSpillAboveDepth && sc.stack_spill != nullptr; }
+static size_t extend_lds_bytes(const DevScene &sc, bool quirk) {
+  return (size_t)((extend_spills(sc, quirk) ? kLdsStackLevels : sc.stack_depth) + kMaxLeafQueue) * 64 * sizeof(uint32_t);
+}
+constexpr int kMaxExtendWaves = 256 * 32;  // 256 CUs x 32 wave slots
 
 // `counts` = entries per region, `work` = claim counters per region (zeroed by the caller); both
 // kCounterStride words apart.
@@ -406,19 +418,22 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
   // a whole number of them per region
   int64_t claims = (n_upper + tune.claim - 1) / tune.claim;
-  int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, 256 * 32));
+  int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, kMaxExtendWaves));
   dim3 g(grid), b(64);
-  size_t lds = extend_lds_bytes(sc);
+  size_t lds = extend_lds_bytes(sc, quirk);
+#define RT_LAUNCH_EXTEND(Q, C, G, S) hipLaunchKernelGGL((k_extend<Q, C, G, S>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
+  const bool spill = extend_spills(sc, quirk);
   if (quirk) {
-    if (counted) hipLaunchKernelGGL((k_extend<true, true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
-    else hipLaunchKernelGGL((k_extend<true, false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    if (counted) RT_LAUNCH_EXTEND(true, true, false, false);
+    else RT_LAUNCH_EXTEND(true, false, false, false);
   } else if (sc.nodes_q) {
-    if (counted) hipLaunchKernelGGL((k_extend<false, true, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
-    else hipLaunchKernelGGL((k_extend<false, false, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true); else RT_LAUNCH_EXTEND(false, true, true, false); }
+    else { if (spill) RT_LAUNCH_EXTEND(false, false, true, true); else RT_LAUNCH_EXTEND(false, false, true, false); }
   } else {
-    if (counted) hipLaunchKernelGGL((k_extend<false, true, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
-    else hipLaunchKernelGGL((k_extend<false, false, false>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters);
+    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, false, true); else RT_LAUNCH_EXTEND(false, true, false, false); }
+    else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true); else RT_LAUNCH_EXTEND(false, false, false, false); }
   }
+#undef RT_LAUNCH_EXTEND
 }
 
 // `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
@@ -1053,6 +1068,8 @@ struct RtSceneHandle {
   size_t events_used = 0;
   RtProgressFn progress = nullptr;
   void *progress_user = nullptr;
+  int32_t n_internal = 0;           // internal nodes resident on the device
+  bool device_built = false;        // the tree was built by rt_hip_scene_build
   void *noalloc_scratch = nullptr;  // this device's address of the file-scope scratch array (rt_hip_trace_rays_noalloc)
 };
 
@@ -1308,28 +1325,15 @@ static int guarded(F &&body) {
   }
 }
 
-static int noalloc_scratch_of(int device, void **out);  // per-device address of the scratch array of rt_hip_trace_rays_noalloc
-
-static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) {
-  g_error.clear();
-  if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
-  *out = nullptr;
-  const bool verbose = getenv("RT_HIP_VERBOSE") != nullptr;
-  auto lap_t0 = std::chrono::steady_clock::now();
-  auto lap = [&](const char *what) {
-    auto now = std::chrono::steady_clock::now();
-    if (verbose) fprintf(stderr, "rt_hip upload: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t0).count());
-    lap_t0 = now;
-  };
-  // ---- validate every index before anything reaches a kernel
-  if (s->n_nodes <= 0 || s->n_elements <= 0 || !s->nodes || !s->elements) return fail(RT_ERR_BAD_ARG, "scene has no nodes or no elements");
+// Element, material and attractor indices of a scene (everything but its nodes).
+static int validate_primitives(const RtScene *s) {
+  if (s->n_elements <= 0 || !s->elements) return fail(RT_ERR_BAD_ARG, "scene has no elements");
   if (s->n_triangles < 0 || s->n_quads < 0 || s->n_spheres < 0 || s->n_materials <= 0 || s->n_attractors < 0 || !s->materials)
     return fail(RT_ERR_BAD_ARG, "negative count or no materials");
   if ((s->n_triangles && !s->triangles) || (s->n_quads && !s->quads) || (s->n_spheres && !s->spheres) || (s->n_attractors && !s->attractors))
     return fail(RT_ERR_BAD_ARG, "count without array");
-  if ((uint32_t)s->n_nodes > kRefIndexMask || (uint32_t)s->n_triangles > kRefIndexMask || (uint32_t)s->n_quads > kRefIndexMask ||
-      (uint32_t)s->n_spheres > kRefIndexMask)
-    return fail(RT_ERR_UNSUPPORTED, "more than 2^28-1 nodes or primitives of one kind");
+  if ((uint32_t)s->n_triangles > kRefIndexMask || (uint32_t)s->n_quads > kRefIndexMask || (uint32_t)s->n_spheres > kRefIndexMask)
+    return fail(RT_ERR_UNSUPPORTED, "more than 2^28-1 primitives of one kind");
   for (int i = 0; i < s->n_elements; i++) {
     RtElementRef e = s->elements[i];
     int lim = e.kind == RT_PRIM_TRIANGLE ? s->n_triangles : e.kind == RT_PRIM_QUAD ? s->n_quads : e.kind == RT_PRIM_SPHERE ? s->n_spheres : -1;
@@ -1350,6 +1354,36 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
     // only spheres and quads can be attractors (elements/mod.rs:68-75); the sampling code has no triangle branch
     if (s->elements[e].kind != RT_PRIM_QUAD && s->elements[e].kind != RT_PRIM_SPHERE)
       return fail(RT_ERR_BAD_ARG, "attractor " + std::to_string(i) + " is not a quad or a sphere");
+  }
+  return RT_OK;
+}
+
+// Global-memory part of the traversal stacks of a tree higher than the LDS part holds: [level][wave][lane].
+static int alloc_stack_spill(RtSceneHandle *h) {
+  h->dev.stack_spill = nullptr;
+  if (h->dev.stack_depth <= kSpillAboveDepth) return RT_OK;
+  return dev_alloc(h, &h->dev.stack_spill, (size_t)(h->dev.stack_depth - kLdsStackLevels) * kMaxExtendWaves * 64);
+}
+
+static int noalloc_scratch_of(int device, void **out);  // per-device address of the scratch array of rt_hip_trace_rays_noalloc
+
+static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) {
+  g_error.clear();
+  if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
+  *out = nullptr;
+  const bool verbose = getenv("RT_HIP_VERBOSE") != nullptr;
+  auto lap_t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    auto now = std::chrono::steady_clock::now();
+    if (verbose) fprintf(stderr, "rt_hip upload: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t0).count());
+    lap_t0 = now;
+  };
+  // ---- validate every index before anything reaches a kernel
+  if (s->n_nodes <= 0 || !s->nodes) return fail(RT_ERR_BAD_ARG, "scene has no nodes");
+  if ((uint32_t)s->n_nodes > kRefIndexMask) return fail(RT_ERR_UNSUPPORTED, "more than 2^28-1 nodes");
+  {
+    int vrc = validate_primitives(s);
+    if (vrc != RT_OK) return vrc;
   }
   // nodes: children must lie after their parent (the reference's vector is
   // preorder), which also rules out cycles; leaves must name a valid element.
@@ -1774,6 +1808,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   h->device = device;
   h->n_elements = s->n_elements;
   h->bvh_depth = max_depth;
+  h->n_internal = n_internal;
   int rc = RT_OK;
   auto step = [&](int r) {
     if (rc == RT_OK) rc = r;
@@ -1795,6 +1830,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   h->dev.n_materials = s->n_materials;
   h->dev.root = ref_of_node(0);
   h->dev.stack_depth = std::max(max_depth, 1);
+  if ((rc = alloc_stack_spill(h)) != RT_OK) return rc;
   h->dev.quirk = boxes_bound_contents ? 0 : 1;
   h->dev.danger = nullptr;
   h->dev.n_danger = 0;
@@ -2225,7 +2261,15 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   return RT_OK;
 }
 
+#include "rt_build_device.h"
+
 // ------------------------------------------------------- the C entry points
+int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out) {
+  return guarded([&] { return scene_build_impl(scene, device, out); });
+}
+int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t capacity, int32_t *n_nodes) {
+  return guarded([&] { return scene_download_tree_impl(handle, nodes, capacity, n_nodes); });
+}
 int rt_hip_scene_upload(const RtScene *scene, int device, RtSceneHandle **out) {
   return guarded([&] { return scene_upload_impl(scene, device, out); });
 }

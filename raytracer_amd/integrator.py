@@ -16,10 +16,20 @@ from . import abi
 class ResidentScene:
     """A scene uploaded to one GPU (rt_hip_scene_upload)."""
 
-    def __init__(self, scene_ptr, device=0):
+    def __init__(self, scene_ptr, device=0, build_on_device=False):
+        """Upload the scene with the host's BVH, or (build_on_device) let the GPU build its own from the primitives."""
         self._h = C.c_void_p()
-        abi.check_hip(abi.hip_lib().rt_hip_scene_upload(scene_ptr, int(device), C.byref(self._h)))
+        fn = abi.hip_lib().rt_hip_scene_build if build_on_device else abi.hip_lib().rt_hip_scene_upload
+        abi.check_hip(fn(scene_ptr, int(device), C.byref(self._h)))
         self.device = int(device)
+
+    def download_tree(self):
+        """The resident tree as an array of RtNode (rt_hip_scene_download_tree)."""
+        n = C.c_int32()
+        abi.check_hip(abi.hip_lib().rt_hip_scene_download_tree(self._h, None, 0, C.byref(n)))
+        nodes = (abi.RtNode * n.value)()
+        abi.check_hip(abi.hip_lib().rt_hip_scene_download_tree(self._h, nodes, n.value, C.byref(n)))
+        return nodes
 
     def close(self):
         if self._h:

@@ -1,0 +1,156 @@
+"""rt_hip_scene_build: the BVH built on the device from the primitives alone (linear BVH over Morton codes), opt-in
+beside the default path that takes the host's reference-order tree.
+
+Checked against the CPU oracle walking the DOWNLOADED device tree (rt_hip_scene_download_tree): hit distances and
+element ids exact, ties included, since ties follow the depth-first leaf order of the tree that is walked.  Against
+the host-built tree the hit distances are still exact; ids may differ only among primitives hit at exactly the same t."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import RenderIntegrator, abi, scenes
+from raytracer_amd.integrator import ResidentScene
+from oracle import oracle
+
+from helpers import c1, knot_scene, noise_gate, random_rays, teapot_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_with_nodes(ri, nodes):
+    """A copy of the prepared scene whose tree is `nodes` (for the oracle)."""
+    s = abi.RtScene()
+    C.memmove(C.byref(s), ri.scene, C.sizeof(abi.RtScene))
+    s.nodes = C.cast(nodes, C.POINTER(abi.RtNode))
+    s.n_nodes = len(nodes)
+    return s
+
+
+def _check_tree(ri, nodes):
+    sc = ri.scene.contents
+    n = sc.n_elements
+    assert len(nodes) == 2 * n - 1
+    leaves = [nd.element_index for nd in nodes if nd.is_leaf]
+    assert sorted(leaves) == list(range(n))                      # every element under exactly one leaf
+    internal = [i for i, nd in enumerate(nodes) if not nd.is_leaf]
+    assert len(internal) == n - 1
+    seen = np.zeros(len(nodes), dtype=np.int32)
+    for i in internal:
+        seen[nodes[i].child_l_index] += 1
+        seen[nodes[i].child_r_index] += 1
+    assert seen[0] == 0 and (seen[1:] == 1).all()                # a tree rooted at node 0
+    # child boxes of leaf children contain the element's true bounds
+    for i in internal[:: max(1, len(internal) // 500)]:
+        nd = nodes[i]
+        for child, mn, mx in ((nd.child_l_index, nd.child_l_min, nd.child_l_max), (nd.child_r_index, nd.child_r_min, nd.child_r_max)):
+            if nodes[child].is_leaf:
+                er = sc.elements[nodes[child].element_index]
+                if er.kind == abi.RT_PRIM_TRIANGLE:
+                    t = sc.triangles[er.index]
+                    v0 = np.array(t.v0.tuple())
+                    pts = [v0, v0 + np.array(t.v0v1.tuple()), v0 + np.array(t.v0v2.tuple())]
+                elif er.kind == abi.RT_PRIM_QUAD:
+                    q = sc.quads[er.index]
+                    q0, u, v = np.array(q.q.tuple()), np.array(q.u.tuple()), np.array(q.v.tuple())
+                    pts = [q0, q0 + u, q0 + v, q0 + u + v]
+                else:
+                    s = sc.spheres[er.index]
+                    c, r = np.array(s.center.tuple()), abs(s.radius)
+                    pts = [c - r, c + r]
+                pts = np.array(pts)
+                assert (pts.min(0) >= np.array(mn[:])).all() and (pts.max(0) <= np.array(mx[:])).all()
+
+
+@pytest.mark.parametrize("which", ["c1", "knot", "tilted", "single"])
+def test_device_built_tree_gives_the_oracles_hits(which, tmp_scene_dir):
+    if which == "c1":
+        ri = c1(width=48, height=48, batch=4)
+    elif which == "knot":
+        ri = knot_scene(tmp_scene_dir, 20000, 64, 64, 4, 1, 1)
+    elif which == "tilted":
+        from test_gpu_parity import _tilted_quad_scene
+        ri = _tilted_quad_scene()
+    else:
+        ri = RenderIntegrator.new({"camera": scenes.camera(), "elements": [scenes.sphere((278, 278, 200), 120, scenes.lambertian(.5, .5, .5))]},
+                                  scenes.config(16, 16, 2, 1, 1)).prepare()
+    dev = ResidentScene(ri.scene, 0, build_on_device=True)
+    nodes = dev.download_tree()
+    if which != "single":
+        _check_tree(ri, nodes)
+    twin = _scene_with_nodes(ri, nodes)
+    o, d = random_rays(150_000, seed=71)
+    pg, tg = dev.trace_rays(o, d)
+    po, to = oracle.trace_rays(C.byref(twin), o, d)
+    assert (po >= 0).mean() > (0.05 if which == "single" else 0.3)
+    assert np.array_equal(tg, to)
+    assert np.array_equal(pg, po)
+    cfg = ri.config.copy()
+    pg, tg = dev.primary_hits(cfg)
+    po, to = oracle.primary_hits(C.byref(twin), cfg)
+    assert np.array_equal(tg, to) and np.array_equal(pg, po)
+    dev.close()
+
+
+def test_device_built_tree_against_the_host_built_one(tmp_scene_dir):
+    """Same closest hits as with the reference-order tree: t exact; ids differ only where two primitives are hit at
+    exactly the same t (the duplicated wall triangles of the reference's scene).  Images agree within noise."""
+    ri = knot_scene(tmp_scene_dir, 20000, 96, 96, 16, 4, 1)
+    host = ri.resident(0)
+    dev = ResidentScene(ri.scene, 0, build_on_device=True)
+    o, d = random_rays(200_000, seed=72)
+    ph, th = host.trace_rays(o, d)
+    pd, td = dev.trace_rays(o, d)
+    assert np.array_equal(th, td)
+    differ = ph != pd
+    assert differ.mean() < 0.2                                    # only rays that end on a doubled wall triangle
+    sc = ri.scene.contents
+    for i in np.flatnonzero(differ)[:200]:                       # each of them is a genuine hit of the other element at the same t
+        e = sc.elements[int(pd[i])]
+        assert e.kind == abi.RT_PRIM_TRIANGLE
+        assert oracle.triangle_hit(sc.triangles[e.index], o[i], d[i], 0.0001, 1.7976931348623157e308) == td[i]
+    cfg = ri.config.copy()
+    a, sa = host.render(cfg)
+    b, sb = dev.render(cfg)
+    other = cfg.copy()
+    other.seed = 99
+    c, _ = host.render(other)
+    # the device tree's image differs from the host tree's by less than a second seed does (duplicates share a material)
+    noise_gate(a["linear"], c["linear"], b["linear"], 0.5)
+    assert abs(int(sa.rays) - int(sb.rays)) <= 1e-3 * sa.rays
+    dev.close()
+
+
+def test_device_build_on_the_reference_teapot_scene():
+    ri = teapot_scene(128, 128, 8, 2, 2)
+    dev = ResidentScene(ri.scene, 0, build_on_device=True)
+    nodes = dev.download_tree()
+    _check_tree(ri, nodes)
+    twin = _scene_with_nodes(ri, nodes)
+    cfg = ri.config.copy()
+    pg, tg = dev.primary_hits(cfg)
+    po, to = oracle.primary_hits_threads(C.byref(twin), cfg, 8)
+    assert np.array_equal(pg, po) and np.array_equal(tg, to)
+    out_g, st = dev.render(cfg)
+    out_o, _ = oracle.render(C.byref(twin), cfg, 16)
+    from helpers import assert_image_parity
+    assert_image_parity(out_g, out_o, "teapot, device-built tree", dev, cfg)
+    dev.close()
+
+
+def test_device_build_rejects_what_it_cannot_build():
+    ri = c1(width=8, height=8, batch=1)
+    sc = ri.scene.contents
+    lib = abi.hip_lib()
+    h = C.c_void_p()
+    s = abi.RtScene()
+    C.memmove(C.byref(s), C.byref(sc), C.sizeof(abi.RtScene))
+    s.n_elements = 0
+    assert lib.rt_hip_scene_build(C.byref(s), 0, C.byref(h)) == abi.RT_ERR_BAD_ARG
+    C.memmove(C.byref(s), C.byref(sc), C.sizeof(abi.RtScene))
+    sph = (abi.RtSphere * sc.n_spheres)()
+    C.memmove(sph, sc.spheres, C.sizeof(sph))
+    sph[0].radius = float("inf")
+    s.spheres = sph
+    assert lib.rt_hip_scene_build(C.byref(s), 0, C.byref(h)) == abi.RT_ERR_UNSUPPORTED and b"finite" in lib.rt_hip_last_error()
+    assert lib.rt_hip_scene_build(C.byref(sc), 99, C.byref(h)) == abi.RT_ERR_BAD_ARG
