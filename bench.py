@@ -343,6 +343,8 @@ def main():
             "node_visits_per_ray": v_int, "leaf_tests_per_ray": v_leaf,
             "node_visits_per_ray_device": v_int_dev, "leaf_tests_per_ray_device": v_leaf_dev,
             "simd_lane_utilisation": {"node_steps": lanes_node, "leaf_tests": lanes_leaf, "all_steps": lanes_useful},
+            "wave_cycle_shares": {k: float(getattr(st_cnt, "wave_cycles_" + k)) / max(st_cnt.wave_cycles_refill + st_cnt.wave_cycles_node + st_cnt.wave_cycles_leaf, 1)
+                                  for k in ("refill", "node", "leaf")},
         }
         if working_set < (256 << 20) and ext:
             # the BVH lives in L2 / Infinity Cache: the kernel is bound by VALU issue on divergent lanes, not by HBM

@@ -245,6 +245,11 @@ typedef struct RtStats {
    * (64 * wave_node_steps / node_visits = average lanes idle-or-busy ratio of the SIMD) */
   uint64_t wave_node_steps;
   uint64_t wave_leaf_steps;
+  /* device, with RT_FLAG_COUNT_VISITS: shader clock cycles the waves of the closest-hit kernel spent, summed over
+   * waves, claiming and loading rays / in node steps / in leaf tests and storing results (waiting included) */
+  uint64_t wave_cycles_refill;
+  uint64_t wave_cycles_node;
+  uint64_t wave_cycles_leaf;
 } RtStats;
 
 typedef struct RtSceneHandle RtSceneHandle;

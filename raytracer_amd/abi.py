@@ -152,6 +152,9 @@ class RtStats(C.Structure):
         ("trace_ms_by_depth", C.c_double * RT_MAX_DEPTH_STATS),
         ("wave_node_steps", C.c_uint64),
         ("wave_leaf_steps", C.c_uint64),
+        ("wave_cycles_refill", C.c_uint64),
+        ("wave_cycles_node", C.c_uint64),
+        ("wave_cycles_leaf", C.c_uint64),
     ]
 
 

@@ -411,8 +411,8 @@ RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, flo
 
 // Ray constants for boxes on the 16-bit grid: the slab distance of grid value q on axis a is
 // (grid_min + q*step - o) / d = q * A + B with A = step/d and B = (grid_min - o)/d, one fma.
-// A and B are rounded from f64 and the fma rounds once more; per axis, e bounds the sum of those
-// errors, and it is folded into the constants: the plane the ray meets first uses B - e, the
+// A and B are computed in f32 and the fma rounds once more; per axis, e bounds the sum of those
+// errors (rayq_axis), and it is folded into the constants: the plane the ray meets first uses B - e, the
 // other one B + e (which of the two grid values that is depends on the sign of A only), so the
 // computed interval contains the exact one.  The widening must be per axis: for a ray almost
 // parallel to an axis |A| and e are huge there, and a single bound would pass every box.
@@ -422,16 +422,19 @@ struct RayQ {
   float bhx, bhy, bhz;  // added to q_max * A
 };
 RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out, float &bl_out, float &bh_out) {
-  double inv = 1.0 / d;
-  double a = step * inv, b = (gmin - o) * inv;
-  // |q*A| <= 65535 |A|; each term is off by at most 2^-24 relative, the result by another 2^-24
-  double e = (65535.0 * fabs(a) + fabs(b)) * 2.4e-7 + 1e-30;
-  if (!(e <= kF64Max)) e = 0.0;  // d == 0: the products are inf/NaN and the axis drops out of min/max
-  a_out = (float)a;
-  double b_near = b - e, b_far = b + e;
-  // a >= 0: q_min gives the near plane; a < 0: q_max does
-  bl_out = a >= 0.0 ? __double2float_rd(b_near) : __double2float_ru(b_far);
-  bh_out = a >= 0.0 ? __double2float_ru(b_far) : __double2float_rd(b_near);
+  // Everything but the subtraction gmin - o (which would cancel in f32) is f32 arithmetic: a ray is set up once
+  // per traversal by the lanes that refill, and three f64 divisions there cost more than the node steps they feed.
+  // Errors, relative to |A| resp. |B|: d -> f32 2^-24, the reciprocal instruction 2^-23, step resp. (gmin - o) -> f32
+  // 2^-24, the product 2^-24, i.e. 2.5 * 2^-23 = 3.0e-7 on each constant; the kernel's fma adds 2^-24 of its
+  // result, |q*A + B| <= 65535 |A| + |B|; rounding B -+ e to f32 another 2^-24 |B|.  Sum < 4.2e-7: e uses 4.8e-7.
+  float inv = __builtin_amdgcn_rcpf((float)d);  // +-inf for a direction component that is zero or below f32's range
+  float a = (float)step * inv, b = (float)(gmin - o) * inv;
+  float e = (65535.0f * fabsf(a) + fabsf(b)) * 4.8e-7f + 1e-30f;
+  if (!(e <= 3.0e38f)) e = 0.0f;  // d == 0: the products are inf/NaN and the axis drops out of min/max
+  a_out = a;
+  // a >= 0: q_min gives the near plane; a < 0: q_max does.  The near plane moves nearer, the far plane farther.
+  bl_out = a >= 0.0f ? b - e : b + e;
+  bh_out = a >= 0.0f ? b + e : b - e;
 }
 RT_DEV RayQ make_rayq(const DevScene &sc, d3 o, d3 d) {
   RayQ r;

@@ -271,6 +271,14 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   trav_begin(sc, tv);
   tv.cur = kDone;
   uint32_t nn = 0, nl = 0, wn = 0, wl = 0;  // lane and wave step counts (COUNT only)
+  unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0, cyc_mark = 0;  // shader cycles of the wave per phase (COUNT only)
+  if (COUNT) cyc_mark = __builtin_amdgcn_s_memtime();
+#define RT_PHASE_END(acc)                                         \
+  if (COUNT) {                                                    \
+    unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+    acc += now_ - cyc_mark;                                       \
+    cyc_mark = now_;                                              \
+  }
 
   for (;;) {
     // ---------------------------------------------------------------- refill
@@ -323,6 +331,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         n_idle = __popcll(__ballot(j == kNoRay));
       }
     }
+    RT_PHASE_END(cyc_refill)
     if (n_idle == 64) {
       if (dry) break;
       continue;  // nothing in flight yet: claim again
@@ -354,6 +363,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SPILL>(tv, sref, leafq);
       }
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
+    RT_PHASE_END(cyc_node)
     // ------------------------------------------------------------ leaf phase
     pending = __ballot(tv.qn > 0) != 0;
     if (pending) {
@@ -376,13 +386,18 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
       __builtin_nontemporal_store(tv.best.ref, &hits.ref[j]);
       j = kNoRay;
     }
+    RT_PHASE_END(cyc_leaf)
   }
+#undef RT_PHASE_END
   if (COUNT) {
     atomicAdd(&visit_counters[0], (unsigned long long)nn);
     atomicAdd(&visit_counters[1], (unsigned long long)nl);
     if (lane == 0) {
       atomicAdd(&visit_counters[3], (unsigned long long)wn);
       atomicAdd(&visit_counters[4], (unsigned long long)wl);
+      atomicAdd(&visit_counters[5], cyc_refill);
+      atomicAdd(&visit_counters[6], cyc_node);
+      atomicAdd(&visit_counters[7], cyc_leaf);
     }
   }
 }
@@ -1900,7 +1915,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
-  constexpr int kTotals = RT_MAX_DEPTH_STATS + 6;
+  constexpr int kTotals = RT_MAX_DEPTH_STATS + 9;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire
   unsigned long long *totals;
   PixelOutputs po{};
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
@@ -2096,6 +2111,9 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     stats->samples = host_totals[RT_MAX_DEPTH_STATS + 3];
     stats->wave_node_steps = host_totals[RT_MAX_DEPTH_STATS + 4];
     stats->wave_leaf_steps = host_totals[RT_MAX_DEPTH_STATS + 5];
+    stats->wave_cycles_refill = host_totals[RT_MAX_DEPTH_STATS + 6];
+    stats->wave_cycles_node = host_totals[RT_MAX_DEPTH_STATS + 7];
+    stats->wave_cycles_leaf = host_totals[RT_MAX_DEPTH_STATS + 8];
     stats->batches = rounds;
     for (const TimedLaunch &t : timeline) {
       float ms = 0.f;
