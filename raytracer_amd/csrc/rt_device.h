@@ -45,6 +45,17 @@ struct __attribute__((aligned(64))) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "node must be one 64-byte record");
 
+// 112-byte internal node with the child boxes as the reference holds them (f64).  Uploaded only for trees in
+// which some box does not bound its contents: there the result of a query depends on exactly which boxes the
+// ray hits (bvh_node_sah.rs:206-250), so the walk that follows the reference's visit rule evaluates
+// Aabb::hit (aabb.rs:187-204) on the reference's own numbers instead of a conservative f32 test.
+struct __attribute__((aligned(16))) DevNodeD {
+  double lmin[3], lmax[3], rmin[3], rmax[3];
+  uint32_t left, right;
+  uint32_t pad[2];
+};
+static_assert(sizeof(DevNodeD) == 112, "f64 node record");
+
 // 32-byte internal node: the same two child boxes on a 16-bit grid spanning the scene's
 // bounds (min corners rounded down, max corners up), + child refs.  Half the bytes of DevNode:
 // the node set of a 100 000-triangle scene (3.2 MB) then fits one XCD's L2.
@@ -93,6 +104,7 @@ struct DevMaterial {
 struct DevScene {
   const DevNode *nodes;
   const DevNodeQ *nodes_q;  // non-null when the 16-bit grid is fine enough for this scene
+  const DevNodeD *nodes_d;  // non-null when some box does not bound its contents (see DevNodeD)
   double grid_min[3], grid_step[3];  // grid value q on axis a stands for grid_min[a] + q * grid_step[a]
   const DevTriangle *triangles;
   const DevTriShade *tri_shade;
@@ -587,6 +599,40 @@ RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, con
     tv.cur = hl ? left : right;
   } else {
     trav_pop_fast<SPILL>(tv, stack);
+  }
+}
+
+// Aabb::hit, aabb.rs:187-204, on the reference's f64 box: per axis the plane the ray meets first is picked by the
+// sign of the inverse direction (ray.rs:38-47: `< 0.0`), f64::max / min return the non-NaN operand like fmax / fmin.
+RT_DEV bool slab_hit_exact(const double *mn, const double *mx, d3 o, d3 inv) {
+  const bool sx = inv.x < 0.0, sy = inv.y < 0.0, sz = inv.z < 0.0;
+  double ray_min = ((sx ? mx[0] : mn[0]) - o.x) * inv.x;
+  double ray_max = ((sx ? mn[0] : mx[0]) - o.x) * inv.x;
+  double y_min = ((sy ? mx[1] : mn[1]) - o.y) * inv.y;
+  double y_max = ((sy ? mn[1] : mx[1]) - o.y) * inv.y;
+  ray_min = fmax(ray_min, y_min);
+  ray_max = fmin(ray_max, y_max);
+  double z_min = ((sz ? mx[2] : mn[2]) - o.z) * inv.z;
+  double z_max = ((sz ? mn[2] : mx[2]) - o.z) * inv.z;
+  ray_min = fmax(ray_min, z_min);
+  ray_max = fmin(ray_max, z_max);
+  return fmax(ray_min, 0.0) <= ray_max;
+}
+// The same step on the f64 records: exactly the boxes the reference enters.
+RT_DEV void trav_node_ref_exact(const DevScene &sc, d3 o, d3 inv, Traversal &tv, uint32_t *stack, int stride) {
+  const DevNodeD &n = sc.nodes_d[tv.cur & kRefIndexMask];
+  bool hl = slab_hit_exact(n.lmin, n.lmax, o, inv);
+  bool hr = slab_hit_exact(n.rmin, n.rmax, o, inv);
+  uint32_t left = n.left, right = n.right;
+  if (hl) {
+    stack[tv.sp * stride] = right | (hr ? kRefFlag : 0u);
+    tv.hitmask &= ~(1ull << tv.sp);
+    tv.sp++;
+    tv.cur = left;
+  } else if (hr) {
+    tv.cur = right;
+  } else {
+    trav_pop<true>(tv, stack, stride);
   }
 }
 

@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   d3 ro = D3(0, 0, 0), rd = D3(0, 0, 1);
   RayF f = {};
   RayQ fq = {};
+  d3 rinv = D3(0, 0, 0);  // 1 / direction in f64: the walk on the reference's own boxes (QUIRK with DevNodeD records)
   Traversal tv;
   trav_begin(sc, tv);
   tv.cur = kDone;
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
           if (GRID) fq = make_rayq(sc, ro, rd);
           else f = make_rayf(ro, rd);
+          if (QUIRK && sc.nodes_d) rinv = D3(1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z);  // ray.rs:38-41
           trav_begin(sc, tv);
           if (tune.pass == 1 && hits_danger_box(sc, ro, rd)) {
             hits.ref[j] = kPending;
@@ -344,7 +346,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
       if (COUNT) wn++;
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
-        if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
+        if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rinv, tv, stack, stride);
+        else if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
         else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
         else trav_node_fast<SPILL>(sc, f, tv, sref);
       }
@@ -1679,6 +1682,25 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
     d.pad[0] = d.pad[1] = 0;
   }
   });
+  // ---- the reference's own f64 boxes, for trees whose result depends on exactly which boxes a ray hits
+  std::vector<DevNodeD> nodes_d;
+  if (!boxes_bound_contents && !getenv("RT_HIP_NO_EXACT_BOXES")) {  // (the switch exists for the test that shows why they are needed)
+    nodes_d.resize((size_t)n_internal);
+    parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
+      for (size_t i = begin; i < end; i++) {
+        const RtNode &n = s->nodes[i];
+        if (n.is_leaf) continue;
+        DevNodeD &d = nodes_d[(size_t)internal_index[i]];
+        for (int a = 0; a < 3; a++) {
+          d.lmin[a] = n.child_l_min[a]; d.lmax[a] = n.child_l_max[a];
+          d.rmin[a] = n.child_r_min[a]; d.rmax[a] = n.child_r_max[a];
+        }
+        d.left = ref_of_node(n.child_l_index);
+        d.right = ref_of_node(n.child_r_index);
+        d.pad[0] = d.pad[1] = 0;
+      }
+    });
+  }
   // ---- the same boxes on a 16-bit grid over the bounds of all child boxes.  Used only by the
   // order-free walk, and only if the grid is fine compared with the boxes: a cell much larger
   // than a typical box would make every box test pass.
@@ -1831,6 +1853,8 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   step(dev_upload(h, &h->dev.nodes, nodes));
   h->dev.nodes_q = nullptr;
   if (!nodes_q.empty()) step(dev_upload(h, &h->dev.nodes_q, nodes_q));
+  h->dev.nodes_d = nullptr;
+  if (!nodes_d.empty()) step(dev_upload(h, &h->dev.nodes_d, nodes_d));
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
   step(dev_upload(h, &h->dev.triangles, tris));
   step(dev_upload(h, &h->dev.tri_shade, tri_shade));

@@ -556,3 +556,52 @@ def test_row_block_shards_reproduce_the_image_and_match_the_oracle(block, world)
             o, _ = oracle.render(ri.scene, cfg, 4)
             assert_image_parity(out, o, f"block {block} rank {rank}/{world}", res, cfg)
     assert rays == st.rays
+
+
+def test_rays_grazing_the_wrong_box_of_a_tilted_quad(monkeypatch):
+    """The reference boxes a quad by two opposite corners (quad.rs:86): a tilted quad sticks out of its box, and
+    whether a ray finds the overhang depends on exactly which boxes it hits.  Rays aimed at the overhang a hair
+    outside the box face (1e-7 ... 1e-3 units) must be decided as the reference's f64 slab test decides them,
+    not as a conservative f32 test would."""
+    ri = _tilted_quad_scene()
+    sc = ri.scene.contents
+    rng = np.random.RandomState(41)
+    origins, dirs = [], []
+    for qi in range(sc.n_quads):
+        q = sc.quads[qi]
+        q0, u, v = np.array(q.q.tuple()), np.array(q.u.tuple()), np.array(q.v.tuple())
+        lo, hi = np.minimum(q0, q0 + u + v), np.maximum(q0, q0 + u + v)      # the reference's box
+        for _ in range(40_000):
+            a, b = rng.uniform(0, 1, 2)
+            p = q0 + a * u + b * v                                            # a point of the quad
+            axis = rng.randint(3)
+            side = hi[axis] if rng.uniform() < 0.5 else lo[axis]
+            # move the point along the quad until it lies a hair beyond that face of the box
+            step_dir = u if abs(u[axis]) > abs(v[axis]) else v
+            if abs(step_dir[axis]) < 1e-9:
+                continue
+            eps = 10.0 ** rng.uniform(-7, -3) * (1 if side == hi[axis] else -1)
+            k = (side + eps - p[axis]) / step_dir[axis]
+            p2 = p + k * step_dir
+            off = rng.normal(size=3) * np.array([40.0, 40.0, 200.0])
+            off[axis] = 0.0                                                    # the ray runs parallel to that face, a hair outside it
+            o = p2 + off
+            origins.append(o)
+            dirs.append(p2 - o)
+    o, d = np.array(origins), np.array(dirs)
+    pg, tg = ri.resident(0).trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    quad_elements = [i for i in range(sc.n_elements) if sc.elements[i].kind == abi.RT_PRIM_QUAD]
+    # most of these rays pass the box a hair outside and the reference never tests the quad; some reach it through
+    # the unchecked right-child entry (bvh_node_sah.rs:215-216)
+    n_quad = int(np.isin(po, quad_elements).sum())
+    assert 100 < n_quad < 0.9 * len(po), n_quad
+    assert np.array_equal(pg, po), f"{(pg != po).sum()} of {len(pg)} rays end on another element"
+    assert np.array_equal(tg, to)
+    # the same walk on conservative f32 boxes enters boxes the reference misses and finds quad hits it does not report
+    from raytracer_amd.integrator import ResidentScene
+    monkeypatch.setenv("RT_HIP_NO_EXACT_BOXES", "1")
+    loose = ResidentScene(ri.scene, 0)
+    pl, tl = loose.trace_rays(o, d)
+    loose.close()
+    assert (pl != po).sum() > 100
