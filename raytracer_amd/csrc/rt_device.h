@@ -13,6 +13,9 @@
 #include "../../include/rt_hip.h"
 
 #define RT_DEV __device__ __forceinline__
+#ifndef RT_PK_FMA
+#define RT_PK_FMA 0
+#endif
 
 namespace rtd {
 
@@ -31,8 +34,14 @@ constexpr uint32_t kRefIndexMask = 0x0fffffffu;
 constexpr uint32_t kRefNone = 0xffffffffu;
 constexpr int kRefKindShift = 29;
 constexpr int kMaxStackDepth = 64;
-constexpr int kLdsStackLevels = 24;  // stack entries per lane held in LDS by the order-free walk once it spills
-constexpr int kSpillAboveDepth = 27; // trees up to this height keep the whole stack in LDS: (27 + 4 leaf-queue levels) x 256 B
+#ifndef RT_LDS_LEVELS
+#define RT_LDS_LEVELS 24
+#endif
+#ifndef RT_SPILL_ABOVE
+#define RT_SPILL_ABOVE 27
+#endif
+constexpr int kLdsStackLevels = RT_LDS_LEVELS;  // stack entries per lane held in LDS by the order-free walk once it spills
+constexpr int kSpillAboveDepth = RT_SPILL_ABOVE; // trees up to this height keep the whole stack in LDS: (27 + 4 leaf-queue levels) x 256 B
                                      // per wave still lets 20 waves (the register limit) share a CU's 160 KB; measured on a
                                      // 2 M-triangle scene: height 26 all in LDS 1243 ms, spilling above 24 levels 1315 ms;
                                      // height 38 all in LDS 1649 ms, 28 levels in LDS 1478 ms, 24 levels 1396 ms
@@ -457,6 +466,17 @@ RT_DEV RayQ make_rayq(const DevScene &sc, d3 o, d3 d) {
 }
 // Conservative slab test on the grid: passes whenever the reference's f64 test on the original
 // box does, and never rejects a box that begins at or before `tmax`.
+// Both planes of an axis in one packed fma: (q_min, q_max) * (A, A) + (B_lo, B_hi).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RT_DEV bool slab_hit_q2(f32x2 qx, f32x2 qy, f32x2 qz, const RayQ &r, float tmax, float &tn_out) {
+  f32x2 tx = __builtin_elementwise_fma(qx, f32x2{r.ax, r.ax}, f32x2{r.blx, r.bhx});
+  f32x2 ty = __builtin_elementwise_fma(qy, f32x2{r.ay, r.ay}, f32x2{r.bly, r.bhy});
+  f32x2 tz = __builtin_elementwise_fma(qz, f32x2{r.az, r.az}, f32x2{r.blz, r.bhz});
+  float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
+  float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+  tn_out = tn;
+  return tn <= fminf(tf, tmax);
+}
 RT_DEV bool slab_hit_q(float qminx, float qminy, float qminz, float qmaxx, float qmaxy, float qmaxz, const RayQ &r, float tmax, float &tn_out) {
   float tlx = fmaf(qminx, r.ax, r.blx), thx = fmaf(qmaxx, r.ax, r.bhx);
   float tly = fmaf(qminy, r.ay, r.bly), thy = fmaf(qmaxy, r.ay, r.bhy);
@@ -668,8 +688,13 @@ RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const 
   float rmaxx = (float)(w1.x >> 16), rmaxy = (float)(w1.y & 0xffffu), rmaxz = (float)(w1.y >> 16);
   uint32_t left = w1.z, right = w1.w;
   float tl, tr;
+#if RT_PK_FMA
+  bool hl = slab_hit_q2(f32x2{lminx, lmaxx}, f32x2{lminy, lmaxy}, f32x2{lminz, lmaxz}, r, tv.tcull, tl);
+  bool hr = slab_hit_q2(f32x2{rminx, rmaxx}, f32x2{rminy, rmaxy}, f32x2{rminz, rmaxz}, r, tv.tcull, tr);
+#else
   bool hl = slab_hit_q(lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, r, tv.tcull, tl);
   bool hr = slab_hit_q(rminx, rminy, rminz, rmaxx, rmaxy, rmaxz, r, tv.tcull, tr);
+#endif
   if (hl && hr) {
     bool swap = tr < tl;
     stack_store<SPILL>(stack, tv.sp, swap ? left : right);
@@ -753,6 +778,38 @@ RT_DEV void trav_test_leaf(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32
     if (QUIRK) tv.hitmask |= (height >= 64) ? ~0ull : ((1ull << height) - 1ull);
     else tv.tcull = __double2float_ru(t);
   }
+}
+
+// The order-free walk's leaf phase tests one kind of primitive at a time: a wave pays for the quad and
+// sphere code once per phase, not in every queue slot in which some lane happens to hold one.
+RT_DEV void trav_accept_fast(const DevScene &sc, Traversal &tv, uint32_t leaf, bool ok, double t) {
+  if (ok && t == tv.best.t && tv.best.ref != kRefNone) ok = tie_goes_to_later_test(sc, leaf, tv.best.ref);
+  if (ok) {
+    tv.best.t = t;
+    tv.best.ref = leaf;
+    tv.tcull = __double2float_ru(t);
+  }
+}
+RT_DEV void trav_test_triangle_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
+  Ray r = {o, d, D3(0, 0, 0)};
+  const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[leaf & kRefIndexMask]);
+  double2 a = p[0], b = p[1], c = p[2], dd = p[3], e = p[4];
+  double t;
+  bool ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);
+  trav_accept_fast(sc, tv, leaf, ok, t);
+}
+RT_DEV void trav_test_quad_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
+  Ray r = {o, d, D3(0, 0, 0)};
+  double t;
+  bool ok = quad_hit(sc.quads[leaf & kRefIndexMask], r, kTMin, tv.best.t, t);
+  trav_accept_fast(sc, tv, leaf, ok, t);
+}
+RT_DEV void trav_test_sphere_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
+  Ray r = {o, d, D3(0, 0, 0)};
+  double t;
+  // leaves arrive out of the reference's order: let an equal t through to the tie rule
+  bool ok = sphere_hit(sc.spheres[leaf & kRefIndexMask], r, kTMin, kF64Max, t) && t <= tv.best.t;
+  trav_accept_fast(sc, tv, leaf, ok, t);
 }
 
 }  // namespace rtd

@@ -235,6 +235,9 @@ constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS
 #define RT_EXTRA_STEPS 1
 #endif
+#ifndef RT_SPLIT_LEAF
+#define RT_SPLIT_LEAF 1
+#endif
 constexpr uint32_t kNoRay = 0xffffffffu;
 
 struct ExtendTuning {
@@ -247,7 +250,8 @@ struct ExtendTuning {
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
-template <bool QUIRK, bool COUNT, bool GRID, bool SPILL>
+template <bool QUIRK, bool COUNT, bool GRID, bool SPILL, int WAVES>
+__attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
                                                 ExtendTuning tune, unsigned long long *visit_counters) {
   const uint32_t lane = threadIdx.x;
@@ -272,6 +276,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   trav_begin(sc, tv);
   tv.cur = kDone;
   uint32_t nn = 0, nl = 0, wn = 0, wl = 0;  // lane and wave step counts (COUNT only)
+  uint32_t d_idle = 0, d_done = 0, d_block = 0;
   unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0, cyc_mark = 0;  // shader cycles of the wave per phase (COUNT only)
   if (COUNT) cyc_mark = __builtin_amdgcn_s_memtime();
 #define RT_PHASE_END(acc)                                         \
@@ -344,6 +349,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     bool pending;
     do {
       if (COUNT) wn++;
+      if (COUNT) { d_idle += j == kNoRay; d_done += j != kNoRay && tv.cur == kDone; d_block += (tv.cur & kRefLeaf) && tv.cur < kWait; }
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
         if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rinv, tv, stack, stride);
@@ -369,7 +375,38 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     RT_PHASE_END(cyc_node)
     // ------------------------------------------------------------ leaf phase
     pending = __ballot(tv.qn > 0) != 0;
-    if (pending) {
+    if (pending && !QUIRK && RT_SPLIT_LEAF) {
+      uint32_t quads = 0, spheres = 0;  // queue slots that hold one
+      for (int k = 0; k < kMaxLeafQueue; k++) {
+        if (!__ballot(k < tv.qn)) break;
+        if (COUNT) wl++;
+        if (k < tv.qn) {
+          if (COUNT) nl++;
+          uint32_t leaf = leafq[k * stride];
+          uint32_t kind = (leaf >> kRefKindShift) & 3u;
+          if (kind == RT_PRIM_TRIANGLE) trav_test_triangle_fast(sc, ro, rd, tv, leaf);
+          else if (kind == RT_PRIM_QUAD) quads |= 1u << k;
+          else spheres |= 1u << k;
+        }
+      }
+      while (__ballot(quads != 0)) {
+        if (COUNT) wl++;
+        if (quads) {
+          int k = __ffs(quads) - 1;
+          quads &= quads - 1;
+          trav_test_quad_fast(sc, ro, rd, tv, leafq[k * stride]);
+        }
+      }
+      while (__ballot(spheres != 0)) {
+        if (COUNT) wl++;
+        if (spheres) {
+          int k = __ffs(spheres) - 1;
+          spheres &= spheres - 1;
+          trav_test_sphere_fast(sc, ro, rd, tv, leafq[k * stride]);
+        }
+      }
+      tv.qn = 0;
+    } else if (pending) {
       for (int k = 0; k < kMaxLeafQueue; k++) {
         if (!__ballot(k < tv.qn)) break;
         if (COUNT) wl++;
@@ -395,6 +432,9 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   if (COUNT) {
     atomicAdd(&visit_counters[0], (unsigned long long)nn);
     atomicAdd(&visit_counters[1], (unsigned long long)nl);
+    atomicAdd(&visit_counters[8], (unsigned long long)d_idle);
+    atomicAdd(&visit_counters[9], (unsigned long long)d_done);
+    atomicAdd(&visit_counters[10], (unsigned long long)d_block);
     if (lane == 0) {
       atomicAdd(&visit_counters[3], (unsigned long long)wn);
       atomicAdd(&visit_counters[4], (unsigned long long)wl);
@@ -421,6 +461,12 @@ static size_t extend_lds_bytes(const DevScene &sc, bool quirk) {
   return (size_t)((extend_spills(sc, quirk) ? kLdsStackLevels : sc.stack_depth) + kMaxLeafQueue) * 64 * sizeof(uint32_t);
 }
 constexpr int kMaxExtendWaves = 256 * 32;  // 256 CUs x 32 wave slots
+constexpr size_t kLdsPerCu = 160 * 1024;
+// Waves per SIMD the kernel's registers are budgeted for (template argument WAVES): the walk is bound by VALU issue with
+// part of its memory latency exposed, and a sixth wave (80 instead of 88 registers, a few loop-invariant values in
+// scratch) hides more of it than the tighter budget costs (C3: 688 -> 654 ms).  Seven waves (72 registers) spill inside the loops
+// (1076 ms).  Six waves need 24 stacks per CU in LDS, so only trees up to height 22 get that variant; the counting and reference-rule
+// variants take what they need.
 
 // `counts` = entries per region, `work` = claim counters per region (zeroed by the caller); both
 // kCounterStride words apart.
@@ -439,17 +485,19 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, kMaxExtendWaves));
   dim3 g(grid), b(64);
   size_t lds = extend_lds_bytes(sc, quirk);
-#define RT_LAUNCH_EXTEND(Q, C, G, S) hipLaunchKernelGGL((k_extend<Q, C, G, S>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
+#define RT_LAUNCH_EXTEND(Q, C, G, S, W) hipLaunchKernelGGL((k_extend<Q, C, G, S, W>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
   const bool spill = extend_spills(sc, quirk);
   if (quirk) {
-    if (counted) RT_LAUNCH_EXTEND(true, true, false, false);
-    else RT_LAUNCH_EXTEND(true, false, false, false);
+    if (counted) RT_LAUNCH_EXTEND(true, true, false, false, 4);
+    else RT_LAUNCH_EXTEND(true, false, false, false, 4);
   } else if (sc.nodes_q) {
-    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true); else RT_LAUNCH_EXTEND(false, true, true, false); }
-    else { if (spill) RT_LAUNCH_EXTEND(false, false, true, true); else RT_LAUNCH_EXTEND(false, false, true, false); }
+    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true, 4); else RT_LAUNCH_EXTEND(false, true, true, false, 4); }
+    else if (spill) RT_LAUNCH_EXTEND(false, false, true, true, 5);
+    else if (lds * 24 <= kLdsPerCu) RT_LAUNCH_EXTEND(false, false, true, false, 6);  // the production kernel on trees up to height 22
+    else RT_LAUNCH_EXTEND(false, false, true, false, 5);
   } else {
-    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, false, true); else RT_LAUNCH_EXTEND(false, true, false, false); }
-    else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true); else RT_LAUNCH_EXTEND(false, false, false, false); }
+    if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, false, true, 4); else RT_LAUNCH_EXTEND(false, true, false, false, 4); }
+    else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true, 5); else RT_LAUNCH_EXTEND(false, false, false, false, 5); }
   }
 #undef RT_LAUNCH_EXTEND
 }
@@ -1939,7 +1987,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
-  constexpr int kTotals = RT_MAX_DEPTH_STATS + 9;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire
+  constexpr int kTotals = RT_MAX_DEPTH_STATS + 13;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire
   unsigned long long *totals;
   PixelOutputs po{};
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
@@ -2138,6 +2186,10 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     stats->wave_cycles_refill = host_totals[RT_MAX_DEPTH_STATS + 6];
     stats->wave_cycles_node = host_totals[RT_MAX_DEPTH_STATS + 7];
     stats->wave_cycles_leaf = host_totals[RT_MAX_DEPTH_STATS + 8];
+    if (getenv("RT_HIP_VERBOSE") && host_totals[RT_MAX_DEPTH_STATS + 4])
+      fprintf(stderr, "[diag] node-step lane slots: idle %.3f done-waiting %.3f blocked-at-leaf %.3f (of 64 x %llu wave steps; only first of the two unrolled steps sampled)\n",
+              host_totals[RT_MAX_DEPTH_STATS + 9] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 10] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]),
+              host_totals[RT_MAX_DEPTH_STATS + 11] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 4]);
     stats->batches = rounds;
     for (const TimedLaunch &t : timeline) {
       float ms = 0.f;
