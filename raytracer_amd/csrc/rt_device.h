@@ -448,10 +448,16 @@ RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out
   // Errors, relative to |A| resp. |B|: d -> f32 2^-24, the reciprocal instruction 2^-23, step resp. (gmin - o) -> f32
   // 2^-24, the product 2^-24, i.e. 2.5 * 2^-23 = 3.0e-7 on each constant; the kernel's fma adds 2^-24 of its
   // result, |q*A + B| <= 65535 |A| + |B|; rounding B -+ e to f32 another 2^-24 |B|.  Sum < 4.2e-7: e uses 4.8e-7.
-  float inv = __builtin_amdgcn_rcpf((float)d);  // +-inf for a direction component that is zero or below f32's range
+  // A direction component that is zero (or below 1e-25) counts as +-1e-25: with an infinite reciprocal q*A + B would be
+  // inf - inf for every box and the axis would drop out of the test altogether -- still conservative, but a ray parallel
+  // to two axes would then enter almost every box of the tree.  With the finite stand-in a box whose slab does not
+  // contain the origin is 1e25 x its distance away (beyond any hit), one that does contains t = 0, and e below, 4.8e-7 of
+  // 1e25 x the scene's extent, covers what the stand-in and the rounding change.
+  float inv = __builtin_amdgcn_rcpf((float)d);
+  inv = fminf(fmaxf(inv, -1e25f), 1e25f);
   float a = (float)step * inv, b = (float)(gmin - o) * inv;
   float e = (65535.0f * fabsf(a) + fabsf(b)) * 4.8e-7f + 1e-30f;
-  if (!(e <= 3.0e38f)) e = 0.0f;  // d == 0: the products are inf/NaN and the axis drops out of min/max
+  if (!(e <= 3.0e38f)) e = 0.0f;  // a scene wider than 1e8 units with such a ray: the products are inf/NaN and the axis drops out of min/max
   a_out = a;
   // a >= 0: q_min gives the near plane; a < 0: q_max does.  The near plane moves nearer, the far plane farther.
   bl_out = a >= 0.0f ? b - e : b + e;
@@ -518,6 +524,14 @@ struct Traversal {
   float tcull;       // !QUIRK: best.t rounded up to f32 (+inf before the first hit)
   Hit best;
 };
+
+// A direction component of exactly -0.0: Ray::new takes its sign as positive (`-0.0 < 0.0` is false, ray.rs:44-46) and its
+// reciprocal as -inf (ray.rs:38), so Aabb::hit pairs the wrong planes (aabb.rs:187-204): inside the slab the interval is
+// (+inf, -inf), beside it both ends are -inf or both +inf, and with at least one finite axis every box fails.  Such a ray
+// misses everything below an internal root.
+RT_DEV bool ray_has_negative_zero(d3 d) {
+  return (d.x == 0.0 && __builtin_signbit(d.x)) || (d.y == 0.0 && __builtin_signbit(d.y)) || (d.z == 0.0 && __builtin_signbit(d.z));
+}
 
 RT_DEV void trav_begin(const DevScene &sc, Traversal &tv) {
   tv.cur = sc.root;
@@ -623,9 +637,9 @@ RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, con
 }
 
 // Aabb::hit, aabb.rs:187-204, on the reference's f64 box: per axis the plane the ray meets first is picked by the
-// sign of the inverse direction (ray.rs:38-47: `< 0.0`), f64::max / min return the non-NaN operand like fmax / fmin.
-RT_DEV bool slab_hit_exact(const double *mn, const double *mx, d3 o, d3 inv) {
-  const bool sx = inv.x < 0.0, sy = inv.y < 0.0, sz = inv.z < 0.0;
+// sign of the direction (ray.rs:44-46: `dir_norm < 0.0`, so -0.0 counts as positive although its reciprocal is -inf), f64::max / min return the non-NaN operand like fmax / fmin.
+RT_DEV bool slab_hit_exact(const double *mn, const double *mx, d3 o, d3 d, d3 inv) {
+  const bool sx = d.x < 0.0, sy = d.y < 0.0, sz = d.z < 0.0;
   double ray_min = ((sx ? mx[0] : mn[0]) - o.x) * inv.x;
   double ray_max = ((sx ? mn[0] : mx[0]) - o.x) * inv.x;
   double y_min = ((sy ? mx[1] : mn[1]) - o.y) * inv.y;
@@ -639,10 +653,10 @@ RT_DEV bool slab_hit_exact(const double *mn, const double *mx, d3 o, d3 inv) {
   return fmax(ray_min, 0.0) <= ray_max;
 }
 // The same step on the f64 records: exactly the boxes the reference enters.
-RT_DEV void trav_node_ref_exact(const DevScene &sc, d3 o, d3 inv, Traversal &tv, uint32_t *stack, int stride) {
+RT_DEV void trav_node_ref_exact(const DevScene &sc, d3 o, d3 d, d3 inv, Traversal &tv, uint32_t *stack, int stride) {
   const DevNodeD &n = sc.nodes_d[tv.cur & kRefIndexMask];
-  bool hl = slab_hit_exact(n.lmin, n.lmax, o, inv);
-  bool hr = slab_hit_exact(n.rmin, n.rmax, o, inv);
+  bool hl = slab_hit_exact(n.lmin, n.lmax, o, d, inv);
+  bool hr = slab_hit_exact(n.rmin, n.rmax, o, d, inv);
   uint32_t left = n.left, right = n.right;
   if (hl) {
     stack[tv.sp * stride] = right | (hr ? kRefFlag : 0u);

@@ -235,6 +235,9 @@ constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS
 #define RT_EXTRA_STEPS 1
 #endif
+#ifndef RT_PROBE_SHADE
+#define RT_PROBE_SHADE 0
+#endif
 #ifndef RT_SPLIT_LEAF
 #define RT_SPLIT_LEAF 1
 #endif
@@ -325,6 +328,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           else f = make_rayf(ro, rd);
           if (QUIRK && sc.nodes_d) rinv = D3(1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z);  // ray.rs:38-41
           trav_begin(sc, tv);
+          if (!(sc.root & kRefLeaf) && ray_has_negative_zero(rd)) tv.cur = kDone;  // retires below as a miss
           if (tune.pass == 1 && hits_danger_box(sc, ro, rd)) {
             hits.ref[j] = kPending;
             j = kNoRay;
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
       if (COUNT) { d_idle += j == kNoRay; d_done += j != kNoRay && tv.cur == kDone; d_block += (tv.cur & kRefLeaf) && tv.cur < kWait; }
       if (!(tv.cur & kRefLeaf)) {
         if (COUNT) nn++;
-        if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rinv, tv, stack, stride);
+        if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rd, rinv, tv, stack, stride);
         else if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
         else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
         else trav_node_fast<SPILL>(sc, f, tv, sref);
@@ -712,7 +716,12 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
     }
 
     // ---- phase B: sample the next direction
+#if RT_PROBE_SHADE == 1
+    if (alive) nd = normal;
+    if (false) {
+#else
     if (alive && mkind == RT_MAT_LAMBERTIAN) {
+#endif
       Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
       d3 dir;
       double pdf_val, spdf;
@@ -2113,7 +2122,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         launch_extend(h->dev, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
                       totals + RT_MAX_DEPTH_STATS + 1);
         HIP_TRY(mark_end());
-        HIP_TRY(mark_begin(1));
+        HIP_TRY(mark_begin(1, k));
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
                            results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
         HIP_TRY(mark_end());
@@ -2191,6 +2200,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
               host_totals[RT_MAX_DEPTH_STATS + 9] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 10] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]),
               host_totals[RT_MAX_DEPTH_STATS + 11] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 4]);
     stats->batches = rounds;
+    double shade_ms_by_depth[RT_MAX_DEPTH_STATS] = {};
     for (const TimedLaunch &t : timeline) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
@@ -2200,9 +2210,15 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         stats->trace_ms_by_depth[t.depth < RT_MAX_DEPTH_STATS ? t.depth : RT_MAX_DEPTH_STATS - 1] += ms;
       } else if (t.kind == 1) {
         stats->shade_kernel_ms += ms;
+        shade_ms_by_depth[t.depth < RT_MAX_DEPTH_STATS ? t.depth : RT_MAX_DEPTH_STATS - 1] += ms;
       } else {
         stats->other_kernel_ms += ms;
       }
+    }
+    if (getenv("RT_HIP_VERBOSE") && timed) {
+      fprintf(stderr, "[rt_hip] k_shade ms by bounce:");
+      for (int k = 0; k < rp.max_depth && k < RT_MAX_DEPTH_STATS; k++) fprintf(stderr, " %.1f", shade_ms_by_depth[k]);
+      fprintf(stderr, "\n");
     }
     stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }

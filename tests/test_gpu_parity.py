@@ -83,6 +83,53 @@ def test_trace_random_rays(tmp_scene_dir):
     assert frac == 1.0 and exact == 1.0, (frac, rel, exact)
 
 
+def test_axis_parallel_rays_match_the_oracle_and_stay_cheap(tmp_scene_dir):
+    """Directions with one or two components exactly zero (also -0.0 and values below f32's range): the reciprocal
+    is infinite, the reference's slab test still decides those axes (aabb.rs:187-204 with ray.rs:38-47), and so
+    must the walk on the 16-bit grid -- an axis that merely dropped out of its test would leave the result right
+    and let a ray parallel to two axes into almost every box of the tree."""
+    import time
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    res = ri.resident(0)
+    rng = np.random.RandomState(11)
+    n = 120_000
+    o = rng.uniform(5.0, 550.0, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    axis = rng.randint(0, 3, size=n)
+    keep_two = rng.rand(n) < 0.5                      # half the rays are parallel to one axis plane, half to one axis
+    zero = np.array([0.0, -0.0, 1e-310, -1e-60])[rng.randint(0, 4, size=n)]
+    for a in range(3):
+        one = (axis == a) & keep_two                   # component a becomes zero
+        d[one, a] = zero[one]
+        two = (axis == a) & ~keep_two                  # the other two become zero
+        for other in ((a + 1) % 3, (a + 2) % 3):
+            d[two, other] = zero[two]
+    # some start exactly on the room's walls and on the planes of the scene's bounding box
+    o[: n // 10, 0] = np.where(rng.rand(n // 10) < 0.5, 0.0, 555.0)
+    pg, tg = res.trace_rays(o, d)
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    # a component of exactly -0.0 makes the reference miss everything (sign taken as positive, reciprocal -inf): so must the device
+    minus_zero = ((d == 0.0) & np.signbit(d)).any(axis=1)
+    assert minus_zero.sum() > n // 8 and (po[minus_zero] == -1).all() and (pg[minus_zero] == -1).all()
+    assert (pg[~minus_zero] >= 0).mean() > 0.7
+    # otherwise identical, but for rays that start exactly on a wall's plane and creep outward by a denormal step: the
+    # reference's box test drops the wall they run along, the conservative boxes keep it -- a genuine hit, never a lost one
+    differ = np.nonzero((pg != po) | (tg != to))[0]
+    assert len(differ) <= 1e-4 * n, len(differ)
+    sc = ri.scene.contents
+    for i in differ:
+        assert pg[i] >= 0 and po[i] < 0 and o[i, 0] in (0.0, 555.0), (i, pg[i], po[i], o[i], d[i])
+        e = sc.elements[int(pg[i])]
+        assert e.kind == abi.RT_PRIM_TRIANGLE
+        assert oracle.triangle_hit(sc.triangles[e.index], o[i], d[i], 0.0001, 1.7976931348623157e308) == tg[i]
+    # the same number of generic rays takes about as long; with an axis dropped these took hundreds of times longer
+    o2, d2 = random_rays(n, seed=12)
+    res.trace_rays(o2, d2)
+    t0 = time.perf_counter(); res.trace_rays(o2, d2); t_generic = time.perf_counter() - t0
+    t0 = time.perf_counter(); res.trace_rays(o, d); t_axis = time.perf_counter() - t0
+    assert t_axis < 10.0 * t_generic + 0.05, (t_axis, t_generic)
+
+
 def _edge_rays(include_room_corners):
     rng = np.random.RandomState(5)
     targets = []
