@@ -133,7 +133,8 @@ def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
     """Roofline figures of the two dominant kernels from the committed counter sums (per ray of the profiled render)
     and this run's event times.  Formulas (Measurement):
       VALU busy  = 4 * SQ_ACTIVE_INST_VALU / (N_SIMD * GRBM_GUI_ACTIVE / 8)        [SQ counts quad-cycles; GRBM sums 8 XCDs]
-      k_extend   bound "valu-issue": frac = VALU busy * share of lanes doing useful work in a wave's steps
+      k_extend   bound "valu-issue": frac = VALU busy * share of the lanes enabled in the issued VALU instructions
+                 (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); without that counter, the instrumented per-step share)
       fabric B/s = (FETCH_SIZE * fetch_factor + WRITE_SIZE) KiB * 1024 / kernel time  -> hbm_frac against 8 TB/s
       L2 B/s     = (TCC_HIT + TCC_MISS) * 128 B / kernel time                        -> l2_frac against 34.5 TB/s
     """
@@ -157,9 +158,16 @@ def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
             "wait_share_of_wave_time": c["SQ_WAIT_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0),
             "profiled_avg_launch_ms": c.get("kernel_avg_launch_ms"), "this_run_kernel_ms": ms,
         }
+        if c.get("SQ_THREAD_CYCLES_VALU"):
+            # the hardware's own count of the lanes enabled in the VALU instructions it issued (rocprof's VALUUtilization);
+            # lanes without work are masked off by the kernels' branches, so enabled = useful
+            out[name]["valu_lane_share"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
     if "k_extend" in out:
-        out["k_extend"]["useful_lane_share"] = lanes_useful
-        out["k_extend"]["valu_issue_frac"] = out["k_extend"]["valu_busy"] * lanes_useful
+        # instrumented render: lanes with a node visit or a primitive test per wave step (every step weighs the same)
+        out["k_extend"]["useful_lane_share_by_steps"] = lanes_useful
+        share = out["k_extend"].get("valu_lane_share", lanes_useful)
+        out["k_extend"]["useful_lane_share"] = share
+        out["k_extend"]["valu_issue_frac"] = out["k_extend"]["valu_busy"] * share
     return out
 
 

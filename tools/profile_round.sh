@@ -18,6 +18,7 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 pass sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS
+pass sq3 SQ_THREAD_CYCLES_VALU
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 if [ -x $R/tools/calib/fetch_calibration ]; then
   timeout -k 10 120 $R/tools/calib/fetch_calibration > $O/calib_plain.jsonl
