@@ -329,8 +329,13 @@ int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t cap
  *   - d_origins, d_directions (3*n doubles each), d_prim_id, d_t (n each) are
  *     DEVICE pointers on the handle's device; results are complete on return.
  *   - n <= RT_NOALLOC_MAX_RAYS, otherwise RT_ERR_UNSUPPORTED (split the batch).
- *   - All calls on one GPU share that GPU's array: calls that overlap on one
- *     GPU (two threads, two handles) race; serialise them. */
+ *   - All calls on one GPU share that GPU's array, which keeps the previous
+ *     call's contents (the library clears what must start at zero).  Within a
+ *     process the library lets one call at a time through per GPU, so calls
+ *     from two threads or on two handles wait for each other instead of
+ *     racing; rt_hip_scene_upload / rt_hip_scene_build trace one ray through
+ *     the same path at set-up, where whatever the runtime prepares at a
+ *     kernel's first launch may allocate. */
 #define RT_NOALLOC_MAX_RAYS 131072
 int rt_hip_trace_rays_noalloc(RtSceneHandle *handle, int64_t n, const double *d_origins,
                               const double *d_directions, int32_t *d_prim_id, double *d_t);

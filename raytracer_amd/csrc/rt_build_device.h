@@ -525,6 +525,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   h->bvh_depth = tree_height;
   h->n_internal = n_internal;
   h->device_built = true;
+  if ((rc = noalloc_warm_up(h)) != RT_OK) return rc;
   if (verbose) {
     auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "rt_hip build: %d elements, height %d, copies in %.1f ms, build %.1f ms, grid %s (boxes %.1f %% larger)\n", n, tree_height,

@@ -1441,6 +1441,7 @@ static int alloc_stack_spill(RtSceneHandle *h) {
 }
 
 static int noalloc_scratch_of(int device, void **out);  // per-device address of the scratch array of rt_hip_trace_rays_noalloc
+static int noalloc_warm_up(RtSceneHandle *h);            // one query through that entry point's kernels, at set-up
 
 static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) {
   g_error.clear();
@@ -1936,6 +1937,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
     h->dev.n_danger = (int32_t)(danger.size() / 6);
   }
   h->dev.camera = s->camera;
+  if ((rc = noalloc_warm_up(h)) != RT_OK) return rc;
   lap("device copies");
   unwind.h = nullptr;
   *out = h;
@@ -2322,6 +2324,7 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 constexpr int kMaxDevices = 64;
 static std::mutex g_noalloc_mutex;
 static void *g_noalloc_ptr[kMaxDevices];  // device address of `scratch` on each device, once known
+static std::mutex g_noalloc_busy[kMaxDevices];  // one query at a time per device: they all use that device's one array
 
 // Device address of `scratch` on `device`, which must be the current device.  Looked up once per
 // device (at scene upload: set-up time, where loading the code object may allocate).
@@ -2348,6 +2351,7 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   if (n == 0) return RT_OK;
   if (!h->noalloc_scratch) return fail(RT_ERR_HIP, "the scene handle has no scratch address");
   HIP_TRY(hipSetDevice(h->device));
+  std::lock_guard<std::mutex> one_at_a_time(g_noalloc_busy[h->device]);
   // carve the device's copy of the array: counters first, then the queue and the hit buffer
   unsigned char *base = static_cast<unsigned char *>(h->noalloc_scratch);
   uint32_t *d_counts = reinterpret_cast<uint32_t *>(base);
@@ -2369,6 +2373,19 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return RT_OK;
+}
+
+// Set-up for rt_hip_trace_rays_noalloc: trace one ray through it now.  Whatever the runtime sets up lazily at a kernel's first
+// launch on a queue (loading the code object, private-segment memory for the few registers the walk keeps there) happens
+// here, where allocating is allowed, and not inside a caller's first query.  The ray and its result live in the last 256 bytes
+// of the scratch array, which a one-ray query does not use otherwise.
+static int noalloc_warm_up(RtSceneHandle *h) {
+  static_assert(kNoAllocBytes > kNoAllocCounterBytes + 64 * kRegions * 60 + 256, "room for the warm-up ray behind a one-ray queue");
+  unsigned char *tail = static_cast<unsigned char *>(h->noalloc_scratch) + kNoAllocBytes - 256;
+  const double ray[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+  HIP_TRY(hipMemcpy(tail, ray, sizeof ray, hipMemcpyHostToDevice));
+  double *d = reinterpret_cast<double *>(tail);
+  return trace_rays_noalloc_impl(h, 1, d, d + 3, reinterpret_cast<int32_t *>(d + 7), d + 6);
 }
 
 #include "rt_build_device.h"

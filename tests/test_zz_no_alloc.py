@@ -64,3 +64,36 @@ def test_noalloc_rejects_sizes_beyond_its_maximum_and_null_buffers():
     assert str(abi.RT_NOALLOC_MAX_RAYS) in msg and "at most" in msg
     assert lib.rt_hip_trace_rays_noalloc(res._h, 5, None, None, None, None) == abi.RT_ERR_BAD_ARG
     assert lib.rt_hip_trace_rays_noalloc(res._h, 0, None, None, None, None) == abi.RT_OK
+
+
+def test_noalloc_calls_from_two_threads_on_two_scenes_wait_for_each_other(tmp_scene_dir):
+    """Both scenes' queries go through the GPU's one array: the library lets one call through at a time."""
+    import threading
+    torch = pytest.importorskip("torch")
+    scenes_ = [knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1), c1(width=8, height=8, batch=1)]
+    res = [ri.resident(0) for ri in scenes_]
+    rays = [random_rays(60_000, seed=51), random_rays(60_000, seed=52)]
+    want = [res[k].trace_rays(*rays[k]) for k in range(2)]
+    bufs = []
+    for k in range(2):
+        o, d = rays[k]
+        bufs.append((torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda(),
+                     torch.empty(o.shape[0], dtype=torch.int32, device="cuda"), torch.empty(o.shape[0], dtype=torch.float64, device="cuda")))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                res[k].trace_rays_noalloc(*bufs[k])
+                if not (np.array_equal(bufs[k][2].cpu().numpy(), want[k][0]) and np.array_equal(bufs[k][3].cpu().numpy(), want[k][1])):
+                    errors.append(k)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
