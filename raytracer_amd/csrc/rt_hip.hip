@@ -235,9 +235,6 @@ constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS
 #define RT_EXTRA_STEPS 1
 #endif
-#ifndef RT_PROBE_SHADE
-#define RT_PROBE_SHADE 0
-#endif
 #ifndef RT_SPLIT_LEAF
 #define RT_SPLIT_LEAF 1
 #endif
@@ -595,12 +592,29 @@ struct PathResults {
   PathRecord *rec;
 };
 
+// One bounce of every path in a queue: the material's response at the hit, the next ray, stream compaction into the next queue.
+// The continuing paths are SORTED BY WHAT THEY DO NEXT before the sampling arithmetic.  Left as the queue has them, a wave pays for
+// every material's sampling code that any of its lanes needs while the lanes of paths that just ended idle (measured that way: 38 %
+// of the lanes enabled in the kernel's VALU instructions).  So a workgroup of four waves classifies 256 paths (phase A), counts the
+// continuing ones by category -- Lambertian by cosine, Lambertian towards an attractor, Metal, Dielectric -- hands each one's state
+// through LDS to the lane at its place in that order, and samples (phase B) with the continuing paths packed into as few waves as
+// they fill, one category per wave except where two meet.  Per-path results do not depend on which lane computes them, and the next
+// queue comes out grouped the same way, which the walk likes: rays aimed at an attractor from neighbouring pixels travel together.
+//  * the hit reference of the NEXT trip is fetched one trip ahead: the shading record it names is then requested together with the
+//    path state instead of one memory latency after it;
+//  * a small material table is staged in LDS: the lookup sits on the dependent chain hit reference -> shading record -> material ->
+//    "does the path go on?";
+//  * a path that ends stores its result at once; wave64 compaction of the survivors: ballot, prefix popcount, one atomic per wave.
+constexpr int kShadeCategories = 4;
+__attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
-                                                uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
-  // a small material table is staged in LDS: the lookup sits on the dependent chain
-  // hit reference -> shading record -> material -> "does the path go on?"
-  constexpr int kLdsMaterials = 256;
+                                                       uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
+  constexpr int kLdsMaterials = 64;
   __shared__ DevMaterial lds_materials[kLdsMaterials];
+  __shared__ double lds_f64[13][256];  // point, normal, throughput, direction (3 each), material parameter
+  __shared__ uint64_t lds_rng[256];
+  __shared__ uint32_t lds_pid[256], lds_bits[256];
+  __shared__ uint32_t lds_counts[kShadeCategories][4];  // continuing paths per category and wave
   const bool staged = sc.n_materials <= kLdsMaterials;
   if (staged) {
     const uint32_t words = (uint32_t)sc.n_materials * (uint32_t)(sizeof(DevMaterial) / 4);
@@ -608,49 +622,43 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       reinterpret_cast<uint32_t *>(lds_materials)[w] = reinterpret_cast<const uint32_t *>(sc.materials)[w];
     __syncthreads();
   }
-  // workgroup b serves region b % kRegions (gridDim is a multiple of kRegions)
   const uint32_t region = blockIdx.x % kRegions;
   const uint32_t n = count_ptr[region * kCounterStride];
-  const uint32_t stride = (gridDim.x / kRegions) * blockDim.x;
-  // round the trip count up to whole waves so every lane reaches the ballot
-  const uint32_t n_round = (n + 63u) & ~63u;
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stride = (gridDim.x / kRegions) * 256u;
+  const uint32_t n_round = (n + 255u) & ~255u;  // whole workgroups: every thread reaches every barrier
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const uint32_t in0 = region * q.cap, out0 = region * out.cap;
   uint32_t *out_counter = out_count + region * kCounterStride;
-  // the hit reference of the NEXT trip is fetched one trip ahead: the shading record it names is
-  // then requested together with the path state instead of one memory latency after it
-  const uint32_t jj0 = (blockIdx.x / kRegions) * blockDim.x + threadIdx.x;
+  const uint32_t jj0 = (blockIdx.x / kRegions) * 256u + threadIdx.x;
   uint32_t ref_ahead = jj0 < n ? hits.ref[in0 + jj0] : kRefNone;
-  for (uint32_t jj = jj0; jj < n_round; jj += stride) {
+  for (uint32_t jj = jj0; jj - threadIdx.x < n_round; jj += stride) {
     const uint32_t j = in0 + jj;
     const uint32_t ref_now = ref_ahead;
     ref_ahead = (jj + stride < n) ? hits.ref[j + stride] : kRefNone;
     // ---- phase A: load, classify, decide whether the path goes on
-    bool alive = false;
-    int32_t mkind = -1;
-    bool front_face = false;
-    d3 normal = D3(0, 0, 1), albedo = D3(0, 0, 0), point = D3(0, 0, 0), d = D3(0, 0, 1), T = D3(0, 0, 0);
-    d3 nd = D3(0, 0, 0), rad = D3(0.0, 0.0, 0.0);
-    double param = 0.0;
-    uint64_t rng = 0;
-    uint32_t pid = 0;
-    if (jj < n) {
-      // every load of the path state is issued before the first use
-      uint32_t ref = ref_now;
-      double t = hits.t[j];
-      pid = q.pid[j];
-      rng = q.rng[j];
-      T = bounce ? D3(q.tx[j], q.ty[j], q.tz[j]) : D3(1.0, 1.0, 1.0);
-      // primary rays of a camera without a lens all start at its centre; k_generate stores no origin then
-      d3 o = (bounce == 0 && sc.camera.defocus_angle <= 0.0) ? ld3(sc.camera.camera_center) : D3(q.ox[j], q.oy[j], q.oz[j]);
-      d = D3(q.dx[j], q.dy[j], q.dz[j]);
-      bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
-      if (ref != kRefNone && !dead_weight) {
-        point = o + d * t;  // Ray::at
-        uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
-        {
+    int cat = -1;  // 0 Lambertian by cosine, 1 Lambertian towards an attractor, 2 Metal, 3 Dielectric
+    {
+      int32_t mkind = -1;
+      bool front_face = false;
+      d3 normal = D3(0, 0, 1), albedo = D3(0, 0, 0), point = D3(0, 0, 0), d = D3(0, 0, 1), T = D3(0, 0, 0), rad = D3(0.0, 0.0, 0.0);
+      double param = 0.0;
+      uint64_t rng = 0;
+      uint32_t pid = 0;
+      if (jj < n) {
+        uint32_t ref = ref_now;
+        double t = hits.t[j];
+        pid = q.pid[j];
+        rng = q.rng[j];
+        T = bounce ? D3(q.tx[j], q.ty[j], q.tz[j]) : D3(1.0, 1.0, 1.0);
+        d3 o = (bounce == 0 && sc.camera.defocus_angle <= 0.0) ? ld3(sc.camera.camera_center) : D3(q.ox[j], q.oy[j], q.oz[j]);
+        d = D3(q.dx[j], q.dy[j], q.dz[j]);
+        bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
+        if (ref != kRefNone && !dead_weight) {
+          point = o + d * t;  // Ray::at
+          uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
           uint32_t mat;
-          if (kind == RT_PRIM_TRIANGLE) {  // one 32-byte record: normal + material index
+          if (kind == RT_PRIM_TRIANGLE) {
             const double2 *p = reinterpret_cast<const double2 *>(&sc.tri_shade[idx]);
             double2 a = p[0], b = p[1];
             normal = D3(a.x, a.y, b.x);
@@ -678,105 +686,149 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
             param = m.param;
             mkind = m.kind;
           }
-        }
-        // every material but the dielectric (white attenuation) scales the throughput by its
-        // albedo first; the product is commutative, so one multiplication serves them all
-        if (mkind != RT_MAT_DIELECTRIC) T = T * albedo;
-        if (mkind == RT_MAT_DIFFUSE_LIGHT) {
-          if (front_face) rad = T;  // diffuse_light.rs:20-29
-        } else if (last_bounce) {
-          // the next ray_color call would run at depth 0 and return black
-        } else if (mkind == RT_MAT_METAL) {  // metal.rs:21-53
-          d3 v = normalized(d);
-          d3 reflected = v - normal * (2.0 * dot(v, normal));
-          d3 dir = reflected + random_unit_vector(rng) * param;
-          if (dot(normal, dir) > 0.0) {
-            nd = normalized(dir);
-            alive = true;
+          if (mkind != RT_MAT_DIELECTRIC) T = T * albedo;
+          if (mkind == RT_MAT_DIFFUSE_LIGHT) {
+            if (front_face) rad = T;  // diffuse_light.rs:20-29
+          } else if (last_bounce) {
+            // the next ray_color call would run at depth 0 and return black
+          } else if (mkind == RT_MAT_METAL) {
+            cat = 2;
+          } else if (mkind == RT_MAT_DIELECTRIC) {
+            cat = 3;
+          } else {
+            cat = 0;
+            // integrator.rs:381-391, MixedPDF ratio 0.5: the draw that picks the density is the path's next one
+            if (sc.n_attractors > 0 && rng_gen_range(rng, 0.0, 1.0) < 0.5) cat = 1;
           }
-        } else {
-          alive = true;  // Lambertian and Dielectric always continue
+        }
+        if (cat < 0) {  // the path ends here
+          double4 rec = {rad.x, rad.y, rad.z, __longlong_as_double((long long)(bounce + 1))};
+          double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
+          dst[0] = make_double2(rec.x, rec.y);
+          dst[1] = make_double2(rec.z, rec.w);
         }
       }
+      // ---- the continuing paths take their places: category by category, wave by wave, lane by lane
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int c = 0; c < kShadeCategories; c++) {
+        unsigned long long m = __ballot(cat == c);
+        if (cat == c) mine = m;
+        if (lane == 0) lds_counts[c][wave] = (uint32_t)__popcll(m);
+      }
+      __syncthreads();
+      uint32_t pos = (uint32_t)__popcll(mine & lt_mask);
+#pragma unroll
+      for (int c = 0; c < kShadeCategories; c++)
+#pragma unroll
+        for (uint32_t w = 0; w < 4; w++) {
+          uint32_t cnt = lds_counts[c][w];
+          if (c < cat || (c == cat && w < wave)) pos += cnt;
+        }
+      if (cat >= 0) {
+        lds_f64[0][pos] = point.x; lds_f64[1][pos] = point.y; lds_f64[2][pos] = point.z;
+        lds_f64[3][pos] = normal.x; lds_f64[4][pos] = normal.y; lds_f64[5][pos] = normal.z;
+        lds_f64[6][pos] = T.x; lds_f64[7][pos] = T.y; lds_f64[8][pos] = T.z;
+        lds_f64[9][pos] = d.x; lds_f64[10][pos] = d.y; lds_f64[11][pos] = d.z;
+        lds_f64[12][pos] = param;
+        lds_rng[pos] = rng;
+        lds_pid[pos] = pid;
+        lds_bits[pos] = (uint32_t)cat | (front_face ? 4u : 0u);
+      }
     }
-    // ---- wave64 stream compaction: ballot, prefix popcount, one atomic per wave.  The atomic
-    // is issued here and its result is not needed before the stores at the end, so its
-    // round trip overlaps the sampling arithmetic below.
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int c = 0; c < kShadeCategories; c++)
+#pragma unroll
+      for (uint32_t w = 0; w < 4; w++) total += lds_counts[c][w];
+    // ---- phase B: thread i samples the i-th continuing path of the workgroup
+    const uint32_t i = threadIdx.x;
+    bool alive = i < total;
+    d3 point = D3(0, 0, 0), nd = D3(0, 0, 0), T = D3(0, 0, 0);
+    uint64_t rng = 0;
+    uint32_t pid = 0;
+    if (alive) {
+      point = D3(lds_f64[0][i], lds_f64[1][i], lds_f64[2][i]);
+      d3 normal = D3(lds_f64[3][i], lds_f64[4][i], lds_f64[5][i]);
+      T = D3(lds_f64[6][i], lds_f64[7][i], lds_f64[8][i]);
+      d3 d = D3(lds_f64[9][i], lds_f64[10][i], lds_f64[11][i]);
+      double param = lds_f64[12][i];
+      rng = lds_rng[i];
+      pid = lds_pid[i];
+      const uint32_t bits = lds_bits[i];
+      const int c = (int)(bits & 3u);
+      const bool front_face = (bits & 4u) != 0;
+      if (c <= 1) {  // Lambertian
+        Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
+        d3 dir;
+        double pdf_val, spdf;
+        if (sc.n_attractors > 0) {
+          if (c == 1) dir = attractor_generate(sc, point, rng);
+          else dir = onb_local_vec(uvw, random_cosine_direction(rng));
+          nd = normalized(dir);
+          d3 nn = normalized(nd);  // both densities normalise the (already unit) direction once more
+          spdf = cosine_pdf_value(uvw, nn);
+          pdf_val = 0.5 * attractor_pdf_value(sc, point, nd, nn) + (1. - 0.5) * spdf;
+        } else {
+          dir = onb_local_vec(uvw, random_cosine_direction(rng));
+          nd = normalized(dir);
+          spdf = cosine_pdf_value(uvw, normalized(nd));
+          pdf_val = spdf;
+        }
+        // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419)
+        d3 Tn = (T * spdf) / pdf_val;  // T already holds throughput * albedo
+        if (has_nan(Tn)) Tn = D3(0., 0., 0.);
+        T = Tn;
+      } else if (c == 2) {  // metal.rs:21-53
+        d3 v = normalized(d);
+        d3 reflected = v - normal * (2.0 * dot(v, normal));
+        d3 dir = reflected + random_unit_vector(rng) * param;
+        if (dot(normal, dir) > 0.0) {
+          nd = normalized(dir);
+        } else {  // absorbed: the path ends black
+          alive = false;
+          double4 rec = {0.0, 0.0, 0.0, __longlong_as_double((long long)(bounce + 1))};
+          double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
+          dst[0] = make_double2(rec.x, rec.y);
+          dst[1] = make_double2(rec.z, rec.w);
+        }
+      } else {  // dielectric.rs:24-66
+        double ratio = front_face ? 1.0 / param : param;
+        d3 unit_direction = normalized(d);
+        d3 minus = unit_direction * -1.0;
+        double cos_theta = fmin(dot(normal, minus), 1.0);
+        double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = ratio * sin_theta > 1.0;
+        bool reflect = cannot_refract;
+        if (!reflect) {  // the draw happens only when refraction is possible
+          double r0 = (1.0 - ratio) / (1.0 + ratio);
+          r0 = r0 * r0;
+          double x1 = 1.0 - cos_theta, x2 = x1 * x1;
+          double refl = r0 + (1.0 - r0) * (x2 * x2 * x1);
+          reflect = refl > rng_gen_f64(rng);
+        }
+        d3 dir;
+        if (reflect) {
+          dir = unit_direction - normal * (2.0 * dot(unit_direction, normal));
+        } else {  // refract_ray, metal.rs:62-68
+          double ct = fmin(dot(normal, unit_direction * -1.0), 1.0);
+          d3 r_out_perp = (unit_direction + normal * ct) * ratio;
+          d3 r_out_parallel = normal * (sqrt(fabs(1.0 - length_squared(r_out_perp))) * -1.0);
+          dir = r_out_perp + r_out_parallel;
+        }
+        nd = normalized(dir);  // attenuation is white
+      }
+    }
+    // ---- wave64 stream compaction and stores
     unsigned long long mask = __ballot(alive);
-    uint32_t base = 0;
-    int leader = mask ? __ffsll((long long)mask) - 1 : 0;
-    if (mask && (int)lane == leader) base = atomicAdd(out_counter, (uint32_t)__popcll(mask));
-
-    // a path that ends here stores its result now, which frees the registers for phase B
-    if (jj < n && !alive) {
-      double4 rec = {rad.x, rad.y, rad.z, __longlong_as_double((long long)(bounce + 1))};
-      double2 *dst = reinterpret_cast<double2 *>(res.rec + pid);
-      dst[0] = make_double2(rec.x, rec.y);
-      dst[1] = make_double2(rec.z, rec.w);
-    }
-
-    // ---- phase B: sample the next direction
-#if RT_PROBE_SHADE == 1
-    if (alive) nd = normal;
-    if (false) {
-#else
-    if (alive && mkind == RT_MAT_LAMBERTIAN) {
-#endif
-      Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
-      d3 dir;
-      double pdf_val, spdf;
-      if (sc.n_attractors > 0) {  // integrator.rs:381-391, MixedPDF ratio 0.5
-        double pick = rng_gen_range(rng, 0.0, 1.0);
-        if (pick < 0.5) dir = attractor_generate(sc, point, rng);
-        else dir = onb_local_vec(uvw, random_cosine_direction(rng));
-        nd = normalized(dir);
-        d3 nn = normalized(nd);  // both densities normalise the (already unit) direction once more
-        spdf = cosine_pdf_value(uvw, nn);
-        pdf_val = 0.5 * attractor_pdf_value(sc, point, nd, nn) + (1. - 0.5) * spdf;
-      } else {
-        dir = onb_local_vec(uvw, random_cosine_direction(rng));
-        nd = normalized(dir);
-        spdf = cosine_pdf_value(uvw, normalized(nd));
-        pdf_val = spdf;
-      }
-      // (attenuation * target * scattering_pdf) / pdf_val, NaN -> black (integrator.rs:413-419).
-      // A zero throughput keeps the path going exactly as the reference keeps tracing it;
-      // with RT_FLAG_EARLY_TERMINATE the next bounce drops it.
-      d3 Tn = (T * spdf) / pdf_val;  // T already holds throughput * albedo
-      if (has_nan(Tn)) Tn = D3(0., 0., 0.);
-      T = Tn;
-    } else if (alive && mkind == RT_MAT_DIELECTRIC) {  // dielectric.rs:24-66
-      double ratio = front_face ? 1.0 / param : param;
-      d3 unit_direction = normalized(d);
-      d3 minus = unit_direction * -1.0;
-      double cos_theta = fmin(dot(normal, minus), 1.0);
-      double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-      bool cannot_refract = ratio * sin_theta > 1.0;
-      bool reflect = cannot_refract;
-      if (!reflect) {  // the draw happens only when refraction is possible
-        double r0 = (1.0 - ratio) / (1.0 + ratio);
-        r0 = r0 * r0;
-        double x1 = 1.0 - cos_theta, x2 = x1 * x1;
-        double refl = r0 + (1.0 - r0) * (x2 * x2 * x1);
-        reflect = refl > rng_gen_f64(rng);
-      }
-      d3 dir;
-      if (reflect) {
-        dir = unit_direction - normal * (2.0 * dot(unit_direction, normal));
-      } else {  // refract_ray, metal.rs:62-68
-        double ct = fmin(dot(normal, unit_direction * -1.0), 1.0);
-        d3 r_out_perp = (unit_direction + normal * ct) * ratio;
-        d3 r_out_parallel = normal * (sqrt(fabs(1.0 - length_squared(r_out_perp))) * -1.0);
-        dir = r_out_perp + r_out_parallel;
-      }
-      nd = normalized(dir);  // attenuation is white
-    }
-
-    // ---- phase C: stores
     if (mask) {
+      uint32_t base = 0;
+      int leader = __ffsll((long long)mask) - 1;
+      if ((int)lane == leader) base = atomicAdd(out_counter, (uint32_t)__popcll(mask));
       base = __shfl(base, leader);
       if (alive) {
-        uint32_t k = out0 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t k = out0 + base + (uint32_t)__popcll(mask & lt_mask);
         out.ox[k] = point.x; out.oy[k] = point.y; out.oz[k] = point.z;
         out.dx[k] = nd.x; out.dy[k] = nd.y; out.dz[k] = nd.z;
         out.tx[k] = T.x; out.ty[k] = T.y; out.tz[k] = T.z;
@@ -2125,6 +2177,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
                       totals + RT_MAX_DEPTH_STATS + 1);
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1, k));
+        static_assert(block == 256, "k_shade sorts per workgroup of four waves");
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
                            results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
         HIP_TRY(mark_end());
