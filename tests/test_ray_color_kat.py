@@ -151,3 +151,54 @@ def test_furnace_with_an_attractor_is_unbiased(where, attractor):
     assert np.allclose(mean, BODY, rtol=0.015, atol=0), mean / BODY
     # and it is the mixture that was sampled: single samples do differ from the plain cosine answer
     assert np.abs(img / BODY - 1).max() > 1e-3
+
+
+def _furnace_walls(h=50.0):
+    return _furnace()[1:7]
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_a_fuzzy_mirror_in_a_furnace_returns_its_albedo_times_l(where):
+    """Metal, fuzz 0.3, met at 45 degrees: n . (reflected + fuzz * unit) >= 0.707 - 0.3 > 0, so no sample is absorbed
+    (metal.rs:43-51) and whatever direction the fuzz gives ends on an emitting wall."""
+    am = (0.9, 0.5, 0.25)
+    s = 16.0
+    mirror = _quad((-s / 2, -s / 2, s / 2), (0, s, 0), (s, 0, -s), scenes.metal(*am, 0.3))   # normal (-1,0,-1)/sqrt(2)
+    ri = _integrator([mirror] + _furnace_walls(), scenes.camera(**FURNACE_CAM))
+    img, st = _render(ri, where)
+    want = np.array(am) * np.array(L)
+    assert np.allclose(img, want, rtol=1e-13, atol=0), np.abs(img / want - 1).max()
+    assert st.rays == 2 * st.samples
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_a_glass_ball_in_a_furnace_is_invisible(where):
+    """Dielectric attenuation is white (dielectric.rs:64): reflected or refracted, every path ends on a wall with throughput 1.
+    (A ray refracted into the ball leaves it at once -- Sphere::hit only takes the nearer root, sphere.rs:120-124 -- so the
+    depth limit is never reached.)"""
+    ri = _integrator([scenes.sphere((0, 0, 0), 5.0, scenes.dielectric(1.5))] + _furnace_walls(), scenes.camera(**FURNACE_CAM))
+    img, st = _render(ri, where)
+    assert np.allclose(img, np.array(L), rtol=1e-13, atol=0), np.abs(img - np.array(L)).max()   # the weighted mean of equal samples rounds
+    assert 2 * st.samples <= st.rays <= 4 * st.samples
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_a_glass_pane_reflects_by_schlick(where):
+    """A dielectric quad seen head-on: cos(theta) ~ 1, so the path reflects with probability r0 + (1 - r0)(1 - cos)^5,
+    r0 = ((1 - 1/1.5) / (1 + 1/1.5))^2 = 0.04 (dielectric.rs:41-60, metal.rs:70-76), back to a light behind the camera, and otherwise
+    goes straight on (refract_ray at normal incidence) to a light behind the pane."""
+    la, lb = (1.0, 0.5, 0.25), (0.0, 2.0, 4.0)
+    pane = _quad((-50, -50, 0), (0, 100, 0), (100, 0, 0), scenes.dielectric(1.5))               # normal -z: front face to the camera
+    behind_pane = _quad((-500, -500, 40), (0, 1000, 0), (1000, 0, 0), scenes.diffuse_light(*la))  # normal -z, met by rays along +z
+    behind_camera = _quad((-500, -500, -40), (1000, 0, 0), (0, 1000, 0), scenes.diffuse_light(*lb))  # normal +z, met by rays along -z
+    ri = _integrator([pane, behind_pane, behind_camera], scenes.camera(**CAM), width=64, height=64, batch=16, max_batches=4)
+    img, st = _render(ri, where)
+    assert st.rays == 2 * st.samples
+    mean = img.reshape(-1, 3).mean(axis=0)
+    # rays leave the camera within 2.5 degrees (+ the sampling offset) of the axis: (1 - cos)^5 < 1e-13
+    r0 = ((1 - 1 / 1.5) / (1 + 1 / 1.5)) ** 2
+    want = (1 - r0) * np.array(la) + r0 * np.array(lb)
+    # 262 144 samples: the reflected share 0.04 is known to +-0.0004 (1 sigma)
+    assert np.allclose(mean, want, rtol=0, atol=4 * 0.0004 * np.abs(np.array(lb) - np.array(la)).max()), (mean, want)
+    share = (mean[2] - la[2]) / (lb[2] - la[2])
+    assert abs(share - r0) < 0.002, share
