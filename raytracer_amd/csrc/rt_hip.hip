@@ -233,7 +233,7 @@ extern __shared__ uint32_t g_lds[];
 
 constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS
-#define RT_EXTRA_STEPS 1
+#define RT_EXTRA_STEPS 2  // node steps a wave takes between two votes, minus one (C3 at six waves: 650 / 645 / 633 / 643 ms for 0..3)
 #endif
 #ifndef RT_SPLIT_LEAF
 #define RT_SPLIT_LEAF 1
@@ -2250,10 +2250,13 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     stats->wave_cycles_refill = host_totals[RT_MAX_DEPTH_STATS + 6];
     stats->wave_cycles_node = host_totals[RT_MAX_DEPTH_STATS + 7];
     stats->wave_cycles_leaf = host_totals[RT_MAX_DEPTH_STATS + 8];
-    if (getenv("RT_HIP_VERBOSE") && host_totals[RT_MAX_DEPTH_STATS + 4])
-      fprintf(stderr, "[diag] node-step lane slots: idle %.3f done-waiting %.3f blocked-at-leaf %.3f (of 64 x %llu wave steps; only first of the two unrolled steps sampled)\n",
-              host_totals[RT_MAX_DEPTH_STATS + 9] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 10] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]),
-              host_totals[RT_MAX_DEPTH_STATS + 11] / (32.0 * host_totals[RT_MAX_DEPTH_STATS + 4]), host_totals[RT_MAX_DEPTH_STATS + 4]);
+    if (getenv("RT_HIP_VERBOSE") && host_totals[RT_MAX_DEPTH_STATS + 4]) {
+      // sampled at the first of the 1 + RT_EXTRA_STEPS node steps between two votes (the reference-rule walk votes after every step)
+      const double sampled_slots = 64.0 * host_totals[RT_MAX_DEPTH_STATS + 4] / (walk == 1 ? 1.0 : 1.0 + RT_EXTRA_STEPS);
+      fprintf(stderr, "[rt_hip] lanes of a node step that are not visiting a node: no ray %.3f, walk over but leaf tests pending %.3f, holding a leaf %.3f\n",
+              host_totals[RT_MAX_DEPTH_STATS + 9] / sampled_slots, host_totals[RT_MAX_DEPTH_STATS + 10] / sampled_slots,
+              host_totals[RT_MAX_DEPTH_STATS + 11] / sampled_slots);
+    }
     stats->batches = rounds;
     double shade_ms_by_depth[RT_MAX_DEPTH_STATS] = {};
     for (const TimedLaunch &t : timeline) {
