@@ -760,7 +760,15 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
       const int c = (int)(bits & 3u);
       const bool front_face = (bits & 4u) != 0;
       if (c <= 1) {  // Lambertian
-        Onb uvw = onb_build_from_w(normal);  // CosinePDF::new
+        // CosinePDF::new builds the whole basis (onb.rs:31-45); a path aimed at an attractor only ever reads its w axis
+        Onb uvw;
+        uvw.w = normalized(normal);
+        uvw.u = uvw.v = D3(0, 0, 0);
+        if (c == 0) {
+          d3 a = (fabs(uvw.w.x) > 0.9) ? D3(0., 1., 0.) : D3(1.0, 0., 0.);
+          uvw.v = normalized(cross(uvw.w, a));
+          uvw.u = cross(uvw.w, uvw.v);
+        }
         d3 dir;
         double pdf_val, spdf;
         if (sc.n_attractors > 0) {
