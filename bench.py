@@ -131,7 +131,7 @@ def rust_crate_check():
 
 def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
     """Roofline figures of the two dominant kernels from the committed counter sums (per ray of the profiled render)
-    and this run's event times.  Formulas (Measurement):
+    and this run's event times.  Formulas:
       VALU busy  = 4 * SQ_ACTIVE_INST_VALU / (N_SIMD * GRBM_GUI_ACTIVE / 8)        [SQ counts quad-cycles; GRBM sums 8 XCDs]
       k_extend   bound "valu-issue": frac = VALU busy * share of the lanes enabled in the issued VALU instructions
                  (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); without that counter, the instrumented per-step share)
