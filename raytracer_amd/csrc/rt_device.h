@@ -91,14 +91,6 @@ struct __attribute__((aligned(32))) DevTriShade {
 };
 static_assert(sizeof(DevTriShade) == 32, "triangle shade record");
 
-// 4-byte word for dropping a triangle leaf before its 80-byte record is fetched: the unit normal of the triangle,
-// n / |n| with n = e1 x e2, as three biased bytes (byte = round(127 c) + 128).  Triangle::hit rejects
-// det < EPSILON (triangle.rs:88) and det = e1 . (d x e2) = -(d . n): a ray whose d . n is positive beyond
-// every rounding error of both computations is rejected by the reference's test whatever else holds
-// (backface_certain).  0x00808080 never culls.  Uploaded only for scenes whose triangle records do not fit the
-// caches, where the walk is bound by HBM bytes and half the leaf tests meet a back face.
-constexpr uint32_t kNeverCull = 0x00808080u;
-
 struct DevQuad {
   double q[3], u[3], v[3], normal[3], w[3];
   double d, area;
@@ -125,7 +117,6 @@ struct DevScene {
   double grid_min[3], grid_step[3];  // grid value q on axis a stands for grid_min[a] + q * grid_step[a]
   const DevTriangle *triangles;
   const DevTriShade *tri_shade;
-  const uint32_t *tri_cull;  // per triangle slot, see kNeverCull; null: every triangle leaf is tested
   const DevQuad *quads;
   const DevSphere *spheres;
   const DevMaterial *materials;
@@ -803,18 +794,6 @@ RT_DEV void trav_test_leaf(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32
   }
 }
 
-// Is the ray certainly on the back of the triangle, i.e. certainly det < 0 in the reference's test?  Error budget, in
-// units of d . n / |n| (the word is made by make_tri_cull at upload):
-//   bytes: |decoded c - c| <= 0.5 / 127 per component, times sum |d_c| <= sqrt 3          < 0.00682
-//   f32 arithmetic on values below 3 * 255                                                  < 0.00001
-//   the f64 test's own rounding error in det, at most 2^-49 |e1|_1 |e2|_1, relative to |n|  <= 0.001 (else the word never culls)
-// A ray is dropped above 0.0085, which leaves 0.0007 spare.  NaN anywhere: not certain, the test decides.
-RT_DEV bool backface_certain(uint32_t w, float dx, float dy, float dz) {
-  float bx = (float)(w & 0xffu), by = (float)((w >> 8) & 0xffu), bz = (float)((w >> 16) & 0xffu);
-  float t = fmaf(dx, bx - 128.0f, fmaf(dy, by - 128.0f, dz * (bz - 128.0f)));  // 127 * d . (decoded normal)
-  return t > 0.0085f * 127.0f;
-}
-
 // The order-free walk's leaf phase tests one kind of primitive at a time: a wave pays for the quad and
 // sphere code once per phase, not in every queue slot in which some lane happens to hold one.
 RT_DEV void trav_accept_fast(const DevScene &sc, Traversal &tv, uint32_t leaf, bool ok, double t) {
@@ -825,17 +804,13 @@ RT_DEV void trav_accept_fast(const DevScene &sc, Traversal &tv, uint32_t leaf, b
     tv.tcull = __double2float_ru(t);
   }
 }
-// Returns whether the triangle's record was fetched and tested.
-template <bool CULL>
-RT_DEV bool trav_test_triangle_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
-  if (CULL && backface_certain(sc.tri_cull[leaf & kRefIndexMask], (float)d.x, (float)d.y, (float)d.z)) return false;
+RT_DEV void trav_test_triangle_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
   Ray r = {o, d, D3(0, 0, 0)};
   const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[leaf & kRefIndexMask]);
   double2 a = p[0], b = p[1], c = p[2], dd = p[3], e = p[4];
   double t;
   bool ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);
   trav_accept_fast(sc, tv, leaf, ok, t);
-  return true;
 }
 RT_DEV void trav_test_quad_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
   Ray r = {o, d, D3(0, 0, 0)};

@@ -250,7 +250,7 @@ struct ExtendTuning {
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
-template <bool QUIRK, bool COUNT, bool GRID, bool SPILL, int WAVES, bool CULL = false>
+template <bool QUIRK, bool COUNT, bool GRID, bool SPILL, int WAVES>
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
                                                 ExtendTuning tune, unsigned long long *visit_counters) {
@@ -382,13 +382,12 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         if (!__ballot(k < tv.qn)) break;
         if (COUNT) wl++;
         if (k < tv.qn) {
+          if (COUNT) nl++;
           uint32_t leaf = leafq[k * stride];
           uint32_t kind = (leaf >> kRefKindShift) & 3u;
-          bool tested = true;
-          if (kind == RT_PRIM_TRIANGLE) tested = trav_test_triangle_fast<CULL>(sc, ro, rd, tv, leaf);
+          if (kind == RT_PRIM_TRIANGLE) trav_test_triangle_fast(sc, ro, rd, tv, leaf);
           else if (kind == RT_PRIM_QUAD) quads |= 1u << k;
           else spheres |= 1u << k;
-          if (COUNT && tested) nl++;
         }
       }
       while (__ballot(quads != 0)) {
@@ -487,16 +486,11 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, kMaxExtendWaves));
   dim3 g(grid), b(64);
   size_t lds = extend_lds_bytes(sc, quirk);
-#define RT_LAUNCH_EXTEND_CULL(Q, C, G, S, W) hipLaunchKernelGGL((k_extend<Q, C, G, S, W, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
 #define RT_LAUNCH_EXTEND(Q, C, G, S, W) hipLaunchKernelGGL((k_extend<Q, C, G, S, W>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
   const bool spill = extend_spills(sc, quirk);
   if (quirk) {
     if (counted) RT_LAUNCH_EXTEND(true, true, false, false, 4);
     else RT_LAUNCH_EXTEND(true, false, false, false, 4);
-  } else if (sc.nodes_q && sc.tri_cull) {  // scenes beyond the caches: back faces are dropped before their records are fetched
-    if (counted) { if (spill) RT_LAUNCH_EXTEND_CULL(false, true, true, true, 4); else RT_LAUNCH_EXTEND_CULL(false, true, true, false, 4); }
-    else if (spill) RT_LAUNCH_EXTEND_CULL(false, false, true, true, 5);
-    else RT_LAUNCH_EXTEND_CULL(false, false, true, false, 5);
   } else if (sc.nodes_q) {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true, 4); else RT_LAUNCH_EXTEND(false, true, true, false, 4); }
     else if (spill) RT_LAUNCH_EXTEND(false, false, true, true, 5);
@@ -507,7 +501,6 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
     else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true, 5); else RT_LAUNCH_EXTEND(false, false, false, false, 5); }
   }
 #undef RT_LAUNCH_EXTEND
-#undef RT_LAUNCH_EXTEND_CULL
 }
 
 // `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
@@ -1501,28 +1494,6 @@ static int validate_primitives(const RtScene *s) {
 }
 
 // Global-memory part of the traversal stacks of a tree higher than the LDS part holds: [level][wave][lane].
-// a x b - c x d with one rounding's worth of error (Kahan's difference of products)
-static double diff_of_products(double a, double b, double c, double d) {
-  double w = c * d;
-  double e = std::fma(-c, d, w);
-  double f = std::fma(a, b, -w);
-  return f + e;
-}
-// The cull word of a triangle (kNeverCull, backface_certain in rt_device.h hold the error budget).
-static uint32_t make_tri_cull(const double *e1, const double *e2) {
-  double n[3] = {diff_of_products(e1[1], e2[2], e1[2], e2[1]), diff_of_products(e1[2], e2[0], e1[0], e2[2]),
-                 diff_of_products(e1[0], e2[1], e1[1], e2[0])};
-  double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-  double m = (std::fabs(e1[0]) + std::fabs(e1[1]) + std::fabs(e1[2])) * (std::fabs(e2[0]) + std::fabs(e2[1]) + std::fabs(e2[2]));
-  if (!(len > 0.0) || !(len <= kF64Max) || !(m * 1.7763568394002505e-15 <= 0.001 * len)) return kNeverCull;  // 2^-49
-  uint32_t w = 0;
-  for (int a = 0; a < 3; a++) w |= (uint32_t)((int)std::rint(n[a] / len * 127.0) + 128) << (8 * a);
-  return w;
-}
-// Triangle records beyond this many bytes do not stay in the Infinity Cache: the walk is then bound by HBM bytes and the
-// cull words (4 bytes per triangle, cache resident) save the record fetch of every back face met.
-constexpr size_t kTriCullAboveBytes = (size_t)256 << 20;
-
 static int alloc_stack_spill(RtSceneHandle *h) {
   h->dev.stack_spill = nullptr;
   if (h->dev.stack_depth <= kSpillAboveDepth) return RT_OK;
@@ -2005,18 +1976,6 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
   step(dev_upload(h, &h->dev.triangles, tris));
   step(dev_upload(h, &h->dev.tri_shade, tri_shade));
-  {
-    bool want_cull = tris.size() * sizeof(DevTriangle) > kTriCullAboveBytes;
-    if (const char *e = getenv("RT_HIP_TRI_CULL")) want_cull = atoi(e) != 0;
-    h->dev.tri_cull = nullptr;
-    if (want_cull && !tris.empty() && fast_walk_exists) {
-      std::vector<uint32_t> cull(tris.size());
-      parallel_for(tris.size(), [&](size_t begin, size_t end) {
-        for (size_t k = begin; k < end; k++) cull[k] = make_tri_cull(tris[k].e1, tris[k].e2);
-      });
-      step(dev_upload(h, &h->dev.tri_cull, cull));
-    }
-  }
   step(dev_upload(h, &h->dev.quads, quads));
   step(dev_upload(h, &h->dev.spheres, spheres));
   step(dev_upload(h, &h->dev.materials, mats));

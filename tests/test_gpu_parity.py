@@ -247,50 +247,6 @@ def test_soup_scene_with_glass_and_metal_triangles(tmp_scene_dir):
     assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
 
 
-def test_back_face_cull_words_change_no_result(monkeypatch, tmp_scene_dir):
-    """Scenes beyond the caches get a 4-byte word per triangle with which a leaf the ray certainly meets from behind is
-    dropped before its record is fetched (Triangle::hit would reject it: det < EPSILON, triangle.rs:88).  Forced on here
-    for small scenes: the same hits and the same image, fewer triangle tests; rays almost in a triangle's plane, where the
-    word must not decide, included."""
-    from raytracer_amd import RenderIntegrator, scenes
-    monkeypatch.setenv("RT_HIP_TRI_CULL", "1")
-    soup = RenderIntegrator.new(scenes.scene_soup(20_000), scenes.config(40, 40, 8, 1, 1)).prepare()
-    knot = knot_scene(tmp_scene_dir, 20000, 48, 48, 4, 2, 1)
-    for ri in (soup, knot):
-        res = ri.resident(0)          # uploaded with the words
-        cfg = ri.config.copy()
-        o, d = random_rays(200_000, seed=29)
-        # a tenth of the rays lie (almost) in the plane of a wall or of a mesh triangle they start next to
-        sc = ri.scene.contents
-        rng = np.random.RandomState(3)
-        k = len(o) // 10
-        tri = rng.randint(0, sc.n_triangles, size=k)
-        v0 = np.array([[sc.triangles[i].v0.x, sc.triangles[i].v0.y, sc.triangles[i].v0.z] for i in tri])
-        e1 = np.array([[sc.triangles[i].v0v1.x, sc.triangles[i].v0v1.y, sc.triangles[i].v0v1.z] for i in tri])
-        e2 = np.array([[sc.triangles[i].v0v2.x, sc.triangles[i].v0v2.y, sc.triangles[i].v0v2.z] for i in tri])
-        n = np.cross(e1, e2)
-        inplane = e1 * rng.uniform(-1, 1, size=(k, 1)) + e2 * rng.uniform(-1, 1, size=(k, 1))
-        tilt = rng.choice([0.0, 1e-12, -1e-12, 1e-6, -1e-6, 1e-3, -1e-3, 0.01, -0.01], size=(k, 1))
-        d[:k] = inplane + tilt * n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-300) * np.linalg.norm(inplane, axis=1, keepdims=True)
-        o[:k] = v0 + 0.3 * e1 + 0.3 * e2 - 0.5 * d[:k]
-        pg, tg = res.trace_rays(o, d)
-        po, to = oracle.trace_rays(ri.scene, o, d)
-        assert np.array_equal(pg, po) and np.array_equal(tg, to)
-        c = cfg.copy()
-        c.flags = abi.RT_FLAG_COUNT_VISITS
-        out_c, st_c = res.render(c)
-        out_o, _ = oracle.render(ri.scene, cfg, 8)
-        assert_image_parity(out_c, out_o, "with cull words", res, cfg)
-        monkeypatch.setenv("RT_HIP_TRI_CULL", "0")
-        plain = type(res)(ri.scene, 0)  # a second upload of the same scene, without the words
-        out_p, st_p = plain.render(c)
-        monkeypatch.setenv("RT_HIP_TRI_CULL", "1")
-        assert np.array_equal(out_p["linear"], out_c["linear"]) and st_p.rays == st_c.rays
-        # the walk is the same (its visit counts vary a little with what the lanes of a wave happen to hold); only tests go
-        assert abs(int(st_c.node_visits) - int(st_p.node_visits)) <= 0.02 * st_p.node_visits
-        assert st_c.leaf_tests < 0.8 * st_p.leaf_tests         # about half the triangle leaves met are back faces
-
-
 def _tilted_quad_scene():
     """A quad that is not axis-aligned: the reference boxes it by two opposite corners only
     (quad.rs:86), so parts of it stick out of its box and whether a ray finds them depends on
