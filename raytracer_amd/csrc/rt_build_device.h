@@ -495,6 +495,9 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   const bool use_grid = o_nodes_q && !getenv("RT_HIP_NO_GRID") && sums[0] <= 1.10 * sums[1];
   h->dev.nodes_q = use_grid ? o_nodes_q : nullptr;
   h->dev.nodes_d = nullptr;
+  h->dev.nodes_w = nullptr;
+  h->dev.root_w = 0;
+  h->dev.stack_depth_w = 1;
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = gridc.mn[a], h->dev.grid_step[a] = gridc.step[a];
 
   // materials and attractors as in an upload

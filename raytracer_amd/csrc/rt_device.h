@@ -74,6 +74,18 @@ struct __attribute__((aligned(32))) DevNodeQ {
 };
 static_assert(sizeof(DevNodeQ) == 32, "quantised node must be one 32-byte record");
 
+// 64-byte wide node: up to four child boxes on the same 16-bit grid, stored plane by plane (word c of `px`
+// holds child c's x planes, min in the low half, max in the high half), + four child refs.  Made at upload by
+// pulling grandchildren up into their grandparent (the child with the largest box is opened first), so a ray
+// takes about half as many dependent node fetches as in the binary tree.  An unused slot has ref kRefNone.
+struct __attribute__((aligned(64))) DevNodeW {
+  uint32_t px[4], py[4], pz[4];
+  uint32_t child[4];
+};
+static_assert(sizeof(DevNodeW) == 64, "wide node must be one 64-byte record");
+constexpr int kWideLdsLevels = 22;  // stack entries per lane the walk on wide nodes keeps in LDS: with the four leaf-queue
+                                    // levels 26 x 256 B per wave, what 24 waves (six per SIMD) can share of a CU's 160 KB
+
 // 80-byte triangle record read by the leaf test (triangle.rs:76-117).
 struct __attribute__((aligned(16))) DevTriangle {
   double v0[3], e1[3], e2[3];
@@ -114,6 +126,9 @@ struct DevScene {
   const DevNode *nodes;
   const DevNodeQ *nodes_q;  // non-null when the 16-bit grid is fine enough for this scene
   const DevNodeD *nodes_d;  // non-null when some box does not bound its contents (see DevNodeD)
+  const DevNodeW *nodes_w;  // non-null when the wide form of the grid nodes was made (order-free walk only)
+  uint32_t root_w;          // ref of the wide root (a leaf ref when the tree is a single leaf)
+  int32_t stack_depth_w;    // stack entries a lane can need on the wide nodes
   double grid_min[3], grid_step[3];  // grid value q on axis a stands for grid_min[a] + q * grid_step[a]
   const DevTriangle *triangles;
   const DevTriShade *tri_shade;
@@ -439,10 +454,14 @@ RT_DEV bool slab_hit_f32(float bminx, float bminy, float bminz, float bmaxx, flo
 // parallel to an axis |A| and e are huge there, and a single bound would pass every box.
 struct RayQ {
   float ax, ay, az;
-  float blx, bly, blz;  // added to q_min * A
-  float bhx, bhy, bhz;  // added to q_max * A
+  float blx, bly, blz;  // added to q_min * A (SORTED: to the grid value of the plane the ray meets first)
+  float bhx, bhy, bhz;  // added to q_max * A (SORTED: to the grid value of the other plane)
+  uint32_t selx, sely, selz;  // SORTED only: byte selectors that bring that first plane's half of a (min | max << 16) word into the low half
 };
-RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out, float &bl_out, float &bh_out) {
+// SORTED: the constants belong to the near and the far plane instead of the min and the max plane, and a selector says which
+// half of a packed (min | max << 16) word is the near one: the node step swaps the halves with one v_perm_b32 and needs no min / max per axis.
+template <bool SORTED = false>
+RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out, float &bl_out, float &bh_out, uint32_t &sel_out) {
   // Everything but the subtraction gmin - o (which would cancel in f32) is f32 arithmetic: a ray is set up once
   // per traversal by the lanes that refill, and three f64 divisions there cost more than the node steps they feed.
   // Errors, relative to |A| resp. |B|: d -> f32 2^-24, the reciprocal instruction 2^-23, step resp. (gmin - o) -> f32
@@ -460,15 +479,34 @@ RT_DEV void rayq_axis(double step, double gmin, double o, double d, float &a_out
   if (!(e <= 3.0e38f)) e = 0.0f;  // a scene wider than 1e8 units with such a ray: the products are inf/NaN and the axis drops out of min/max
   a_out = a;
   // a >= 0: q_min gives the near plane; a < 0: q_max does.  The near plane moves nearer, the far plane farther.
-  bl_out = a >= 0.0f ? b - e : b + e;
-  bh_out = a >= 0.0f ? b + e : b - e;
+  if (SORTED) {
+    bl_out = b - e;
+    bh_out = b + e;
+    sel_out = a >= 0.0f ? 0x03020100u : 0x01000302u;
+  } else {
+    bl_out = a >= 0.0f ? b - e : b + e;
+    bh_out = a >= 0.0f ? b + e : b - e;
+    sel_out = 0;
+  }
 }
+template <bool SORTED = false>
 RT_DEV RayQ make_rayq(const DevScene &sc, d3 o, d3 d) {
   RayQ r;
-  rayq_axis(sc.grid_step[0], sc.grid_min[0], o.x, d.x, r.ax, r.blx, r.bhx);
-  rayq_axis(sc.grid_step[1], sc.grid_min[1], o.y, d.y, r.ay, r.bly, r.bhy);
-  rayq_axis(sc.grid_step[2], sc.grid_min[2], o.z, d.z, r.az, r.blz, r.bhz);
+  rayq_axis<SORTED>(sc.grid_step[0], sc.grid_min[0], o.x, d.x, r.ax, r.blx, r.bhx, r.selx);
+  rayq_axis<SORTED>(sc.grid_step[1], sc.grid_min[1], o.y, d.y, r.ay, r.bly, r.bhy, r.sely);
+  rayq_axis<SORTED>(sc.grid_step[2], sc.grid_min[2], o.z, d.z, r.az, r.blz, r.bhz, r.selz);
   return r;
+}
+// The same test on packed words (min | max << 16 per axis) with a SORTED ray: the halves are put in near / far order first.
+RT_DEV bool slab_hit_qs(uint32_t wx, uint32_t wy, uint32_t wz, const RayQ &r, float tmax, float &tn_out) {
+  const uint32_t px = __builtin_amdgcn_perm(wx, wx, r.selx), py = __builtin_amdgcn_perm(wy, wy, r.sely), pz = __builtin_amdgcn_perm(wz, wz, r.selz);
+  float nx = fmaf((float)(px & 0xffffu), r.ax, r.blx), fx = fmaf((float)(px >> 16), r.ax, r.bhx);
+  float ny = fmaf((float)(py & 0xffffu), r.ay, r.bly), fy = fmaf((float)(py >> 16), r.ay, r.bhy);
+  float nz = fmaf((float)(pz & 0xffffu), r.az, r.blz), fz = fmaf((float)(pz >> 16), r.az, r.bhz);
+  float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+  float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
+  tn_out = tn;
+  return tn <= tf;
 }
 // Conservative slab test on the grid: passes whenever the reference's f64 test on the original
 // box does, and never rejects a box that begins at or before `tmax`.
@@ -533,8 +571,8 @@ RT_DEV bool ray_has_negative_zero(d3 d) {
   return (d.x == 0.0 && __builtin_signbit(d.x)) || (d.y == 0.0 && __builtin_signbit(d.y)) || (d.z == 0.0 && __builtin_signbit(d.z));
 }
 
-RT_DEV void trav_begin(const DevScene &sc, Traversal &tv) {
-  tv.cur = sc.root;
+RT_DEV void trav_begin(uint32_t root, Traversal &tv) {
+  tv.cur = root;
   tv.sp = 0;
   tv.qn = 0;
   tv.hitmask = 0;
@@ -551,24 +589,24 @@ struct StackRef {
   uint32_t *spill;   // this lane's slot of the first spilled level; levels are `spill_stride` entries apart
   uint32_t spill_stride;
 };
-template <bool SPILL>
+template <bool SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void stack_store(const StackRef &s, int level, uint32_t v) {
-  if (!SPILL || level < kLdsStackLevels) s.lds[level * 64] = v;
-  else s.spill[(size_t)(level - kLdsStackLevels) * s.spill_stride] = v;
+  if (!SPILL || level < LDSL) s.lds[level * 64] = v;
+  else s.spill[(size_t)(level - LDSL) * s.spill_stride] = v;
 }
-template <bool SPILL>
+template <bool SPILL, int LDSL = kLdsStackLevels>
 RT_DEV uint32_t stack_load(const StackRef &s, int level) {
-  if (!SPILL || level < kLdsStackLevels) return s.lds[level * 64];
-  return s.spill[(size_t)(level - kLdsStackLevels) * s.spill_stride];
+  if (!SPILL || level < LDSL) return s.lds[level * 64];
+  return s.spill[(size_t)(level - LDSL) * s.spill_stride];
 }
 // the order-free walk's pop: entries are children whose box the ray hits
-template <bool SPILL>
+template <bool SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void trav_pop_fast(Traversal &tv, const StackRef &s) {
   if (tv.sp == 0) {
     tv.cur = kDone;
   } else {
     tv.sp--;
-    tv.cur = stack_load<SPILL>(s, tv.sp);
+    tv.cur = stack_load<SPILL, LDSL>(s, tv.sp);
   }
 }
 
@@ -721,12 +759,57 @@ RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const 
   }
 }
 
-// Queue the leaf in `cur` for the next leaf phase and move on (order-free walk).
+// The node step on the 64-byte wide records (order-free walk only): four box tests behind one memory round trip.
+// A child that is a leaf goes straight into the leaf queue while there is room; of the others the nearest is
+// entered and the rest are pushed.  Which children are entered in which order cannot change the result.
 template <bool SPILL>
+RT_DEV void trav_node_w(const DevScene &sc, const RayQ &r, Traversal &tv, const StackRef &stack, uint32_t *leafq, int leafq_cap) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(&sc.nodes_w[tv.cur & kRefIndexMask]);
+  const uint4 wx = p[0], wy = p[1], wz = p[2], rf = p[3];
+  float t0, t1, t2, t3;
+#define RT_WIDE_CHILD(X, Y, Z, T) slab_hit_qs(X, Y, Z, r, tv.tcull, T)
+  bool h0 = RT_WIDE_CHILD(wx.x, wy.x, wz.x, t0);
+  bool h1 = RT_WIDE_CHILD(wx.y, wy.y, wz.y, t1);
+  bool h2 = RT_WIDE_CHILD(wx.z, wy.z, wz.z, t2) && rf.z != kRefNone;  // a node has at least two children
+  bool h3 = RT_WIDE_CHILD(wx.w, wy.w, wz.w, t3) && rf.w != kRefNone;
+#undef RT_WIDE_CHILD
+  // leaves into the queue
+#define RT_WIDE_LEAF(H, REF)                               \
+  if (H && ((REF) & kRefLeaf) && tv.qn < leafq_cap) {      \
+    leafq[tv.qn * 64] = (REF);                             \
+    tv.qn++;                                               \
+    H = false;                                             \
+  }
+  RT_WIDE_LEAF(h0, rf.x)
+  RT_WIDE_LEAF(h1, rf.y)
+  RT_WIDE_LEAF(h2, rf.z)
+  RT_WIDE_LEAF(h3, rf.w)
+#undef RT_WIDE_LEAF
+  // the nearest of the rest: entry distances are >= 0, so their bit patterns order like unsigned integers; the two
+  // lowest bits carry the slot
+  const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xffffffffu;
+  const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xffffffffu;
+  const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xffffffffu;
+  const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xffffffffu;
+  const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+  if (kmin == 0xffffffffu) {
+    trav_pop_fast<SPILL, kWideLdsLevels>(tv, stack);
+    return;
+  }
+  const uint32_t ni = kmin & 3u;
+  if (h0 && ni != 0u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.x); tv.sp++; }
+  if (h1 && ni != 1u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.y); tv.sp++; }
+  if (h2 && ni != 2u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.z); tv.sp++; }
+  if (h3 && ni != 3u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.w); tv.sp++; }
+  tv.cur = ni == 0u ? rf.x : ni == 1u ? rf.y : ni == 2u ? rf.z : rf.w;
+}
+
+// Queue the leaf in `cur` for the next leaf phase and move on (order-free walk).
+template <bool SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void trav_defer_leaf_fast(Traversal &tv, const StackRef &stack, uint32_t *leafq) {
   leafq[tv.qn * 64] = tv.cur;
   tv.qn++;
-  trav_pop_fast<SPILL>(tv, stack);
+  trav_pop_fast<SPILL, LDSL>(tv, stack);
 }
 
 // Queue the leaf in `cur` for the next leaf phase and move on.

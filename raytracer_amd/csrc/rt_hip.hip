@@ -235,6 +235,9 @@ constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS
 #define RT_EXTRA_STEPS 2  // node steps a wave takes between two votes, minus one (C3 at six waves: 650 / 645 / 633 / 643 ms for 0..3)
 #endif
+#ifndef RT_EXTRA_STEPS_WIDE
+#define RT_EXTRA_STEPS_WIDE 1  // the same for the walk on wide nodes
+#endif
 #ifndef RT_SPLIT_LEAF
 #define RT_SPLIT_LEAF 1
 #endif
@@ -250,7 +253,7 @@ struct ExtendTuning {
   int pass;      // 0: every ray; 1: leave rays near an out-of-box primitive to pass 2 (mark them kPending); 2: only those
 };
 
-template <bool QUIRK, bool COUNT, bool GRID, bool SPILL, int WAVES>
+template <bool QUIRK, bool COUNT, bool GRID, bool SPILL, int WAVES, bool WIDE = false>
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work,
                                                 ExtendTuning tune, unsigned long long *visit_counters) {
@@ -258,7 +261,10 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int stride = 64;
   uint32_t *stack = g_lds + lane;
-  const int lds_levels = SPILL ? kLdsStackLevels : sc.stack_depth;
+  static_assert(!WIDE || (GRID && !QUIRK), "wide nodes exist on the grid, for the order-free walk");
+  constexpr int kLdsl = WIDE ? kWideLdsLevels : kLdsStackLevels;
+  const uint32_t root = WIDE ? sc.root_w : sc.root;
+  const int lds_levels = SPILL ? kLdsl : (WIDE ? sc.stack_depth_w : sc.stack_depth);
   uint32_t *leafq = g_lds + (size_t)lds_levels * 64 + lane;
   const StackRef sref = {stack, SPILL ? sc.stack_spill + (size_t)blockIdx.x * 64 + lane : nullptr, gridDim.x * 64u};
   const uint32_t home = blockIdx.x % kRegions;
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   RayQ fq = {};
   d3 rinv = D3(0, 0, 0);  // 1 / direction in f64: the walk on the reference's own boxes (QUIRK with DevNodeD records)
   Traversal tv;
-  trav_begin(sc, tv);
+  trav_begin(root, tv);
   tv.cur = kDone;
   uint32_t nn = 0, nl = 0, wn = 0, wl = 0;  // lane and wave step counts (COUNT only)
   uint32_t d_idle = 0, d_done = 0, d_block = 0;
@@ -321,11 +327,12 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           if (tune.shared_origin) ro = ld3(sc.camera.camera_center);
           else ro = D3(__builtin_nontemporal_load(&q.ox[j]), __builtin_nontemporal_load(&q.oy[j]), __builtin_nontemporal_load(&q.oz[j]));
           rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
-          if (GRID) fq = make_rayq(sc, ro, rd);
+          if (WIDE) fq = make_rayq<true>(sc, ro, rd);
+          else if (GRID) fq = make_rayq(sc, ro, rd);
           else f = make_rayf(ro, rd);
           if (QUIRK && sc.nodes_d) rinv = D3(1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z);  // ray.rs:38-41
-          trav_begin(sc, tv);
-          if (!(sc.root & kRefLeaf) && ray_has_negative_zero(rd)) tv.cur = kDone;  // retires below as a miss
+          trav_begin(root, tv);
+          if (!(root & kRefLeaf) && ray_has_negative_zero(rd)) tv.cur = kDone;  // retires below as a miss
           if (tune.pass == 1 && hits_danger_box(sc, ro, rd)) {
             hits.ref[j] = kPending;
             j = kNoRay;
@@ -355,22 +362,24 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         if (COUNT) nn++;
         if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rd, rinv, tv, stack, stride);
         else if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
+        else if (WIDE) trav_node_w<SPILL>(sc, fq, tv, sref, leafq, tune.leafq);
         else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
         else trav_node_fast<SPILL>(sc, f, tv, sref);
       }
       if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) {
         if (QUIRK) trav_defer_leaf<true>(tv, stack, leafq, stride);
-        else trav_defer_leaf_fast<SPILL>(tv, sref, leafq);
+        else trav_defer_leaf_fast<SPILL, kLdsl>(tv, sref, leafq);
       }
 #pragma unroll
-      for (int extra = 0; extra < (QUIRK ? 0 : RT_EXTRA_STEPS); extra++) {  // more steps before the wave votes again
+      for (int extra = 0; extra < (QUIRK ? 0 : WIDE ? RT_EXTRA_STEPS_WIDE : RT_EXTRA_STEPS); extra++) {  // more steps before the wave votes again
         if (COUNT) wn++;
         if (!(tv.cur & kRefLeaf)) {
           if (COUNT) nn++;
-          if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
+          if (WIDE) trav_node_w<SPILL>(sc, fq, tv, sref, leafq, tune.leafq);
+          else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
           else trav_node_fast<SPILL>(sc, f, tv, sref);
         }
-        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SPILL>(tv, sref, leafq);
+        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SPILL, kLdsl>(tv, sref, leafq);
       }
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
     RT_PHASE_END(cyc_node)
@@ -457,9 +466,15 @@ static ExtendTuning extend_tuning() {
 }
 
 // The walk that follows the reference's rule keeps its whole stack in LDS; the order-free walk at most kLdsStackLevels levels.
-static bool extend_spills(const DevScene &sc, bool quirk) { return !quirk && sc.stack_depth > kSpillAboveDepth && sc.stack_spill != nullptr; }
+static bool extend_wide(const DevScene &sc, bool quirk) { return !quirk && sc.nodes_w != nullptr; }
+static bool extend_spills(const DevScene &sc, bool quirk) {
+  if (extend_wide(sc, quirk)) return sc.stack_depth_w > kWideLdsLevels;
+  return !quirk && sc.stack_depth > kSpillAboveDepth && sc.stack_spill != nullptr;
+}
 static size_t extend_lds_bytes(const DevScene &sc, bool quirk) {
-  return (size_t)((extend_spills(sc, quirk) ? kLdsStackLevels : sc.stack_depth) + kMaxLeafQueue) * 64 * sizeof(uint32_t);
+  const bool wide = extend_wide(sc, quirk);
+  const int levels = extend_spills(sc, quirk) ? (wide ? kWideLdsLevels : kLdsStackLevels) : (wide ? sc.stack_depth_w : sc.stack_depth);
+  return (size_t)(levels + kMaxLeafQueue) * 64 * sizeof(uint32_t);
 }
 constexpr int kMaxExtendWaves = 256 * 32;  // 256 CUs x 32 wave slots
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -491,6 +506,14 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   if (quirk) {
     if (counted) RT_LAUNCH_EXTEND(true, true, false, false, 4);
     else RT_LAUNCH_EXTEND(true, false, false, false, 4);
+  } else if (sc.nodes_w) {
+    static const int wide_waves = getenv("RT_HIP_WIDE_WAVES") ? atoi(getenv("RT_HIP_WIDE_WAVES")) : 5;  // 100 000 triangles: 690 ms at five waves per SIMD, 719 at six
+#define RT_LAUNCH_WIDE(C, S, W) hipLaunchKernelGGL((k_extend<false, C, true, S, W, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
+    if (counted) { if (spill) RT_LAUNCH_WIDE(true, true, 4); else RT_LAUNCH_WIDE(true, false, 4); }
+    else if (wide_waves >= 6 && lds * 24 <= kLdsPerCu) { if (spill) RT_LAUNCH_WIDE(false, true, 6); else RT_LAUNCH_WIDE(false, false, 6); }
+    else if (wide_waves == 5) { if (spill) RT_LAUNCH_WIDE(false, true, 5); else RT_LAUNCH_WIDE(false, false, 5); }
+    else { if (spill) RT_LAUNCH_WIDE(false, true, 4); else RT_LAUNCH_WIDE(false, false, 4); }
+#undef RT_LAUNCH_WIDE
   } else if (sc.nodes_q) {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true, 4); else RT_LAUNCH_EXTEND(false, true, true, false, 4); }
     else if (spill) RT_LAUNCH_EXTEND(false, false, true, true, 5);
@@ -1496,8 +1519,10 @@ static int validate_primitives(const RtScene *s) {
 // Global-memory part of the traversal stacks of a tree higher than the LDS part holds: [level][wave][lane].
 static int alloc_stack_spill(RtSceneHandle *h) {
   h->dev.stack_spill = nullptr;
-  if (h->dev.stack_depth <= kSpillAboveDepth) return RT_OK;
-  return dev_alloc(h, &h->dev.stack_spill, (size_t)(h->dev.stack_depth - kLdsStackLevels) * kMaxExtendWaves * 64);
+  int levels = h->dev.stack_depth > kSpillAboveDepth ? h->dev.stack_depth - kLdsStackLevels : 0;
+  if (h->dev.nodes_w) levels = std::max(levels, h->dev.stack_depth_w - kWideLdsLevels);
+  if (levels <= 0) return RT_OK;
+  return dev_alloc(h, &h->dev.stack_spill, (size_t)levels * kMaxExtendWaves * 64);
 }
 
 static int noalloc_scratch_of(int device, void **out);  // per-device address of the scratch array of rt_hip_trace_rays_noalloc
@@ -1889,6 +1914,91 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
       if (!(total_growth <= 1.10 * total_size)) nodes_q.clear();
     }
   }
+  // ---- wide nodes: up to four children per node, made from the grid nodes by opening, largest box first, the
+  // internal children of a node until four boxes are held (or only leaves are left)
+  std::vector<DevNodeW> nodes_w;
+  int32_t stack_depth_w = 1;
+  // Measured (one MI355X): the walk fetches half as many node records on them (100 000 triangles: 14.7 -> 7.0 per ray) but the
+  // same bytes, and is no faster while the binary records stay in the caches (k_extend 633 -> 690 ms; 2 M triangles 1115 -> 1180 ms);
+  // on a 10 M-triangle soup, whose 320 MB of node records do not, it is 6 % faster.  Hence: made for trees above 256 MB of binary
+  // records, RT_HIP_WIDE=1 / 0 forces them on / off.
+  const char *wide_env = getenv("RT_HIP_WIDE");
+  const bool wide_wanted = wide_env ? atoi(wide_env) != 0 : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)256 << 20);
+  if (!nodes_q.empty() && !s->nodes[0].is_leaf && wide_wanted) {
+    struct Child {
+      uint16_t mn[3], mx[3];
+      uint32_t ref;
+    };
+    struct Item {
+      uint32_t bin, wide;
+    };
+    auto left_of = [](const DevNodeQ &q) { return Child{{q.lmin[0], q.lmin[1], q.lmin[2]}, {q.lmax[0], q.lmax[1], q.lmax[2]}, q.left}; };
+    auto right_of = [](const DevNodeQ &q) { return Child{{q.rmin[0], q.rmin[1], q.rmin[2]}, {q.rmax[0], q.rmax[1], q.rmax[2]}, q.right}; };
+    auto area_of = [&](const Child &c) {
+      double dx = (c.mx[0] - c.mn[0]) * grid_step[0], dy = (c.mx[1] - c.mn[1]) * grid_step[1], dz = (c.mx[2] - c.mn[2]) * grid_step[2];
+      return dx * dy + dy * dz + dz * dx;
+    };
+    nodes_w.reserve((size_t)n_internal / 2 + 1);
+    std::vector<Item> todo;
+    nodes_w.emplace_back();
+    todo.push_back({(uint32_t)internal_index[0], 0u});
+    while (!todo.empty()) {
+      Item it = todo.back();
+      todo.pop_back();
+      Child ch[4];
+      int n = 2;
+      ch[0] = left_of(nodes_q[it.bin]);
+      ch[1] = right_of(nodes_q[it.bin]);
+      while (n < 4) {
+        int best = -1;
+        double best_area = -1.0;
+        for (int i = 0; i < n; i++)
+          if (!(ch[i].ref & kRefLeaf)) {
+            double a = area_of(ch[i]);
+            if (a > best_area) best_area = a, best = i;
+          }
+        if (best < 0) break;
+        const DevNodeQ &open = nodes_q[ch[best].ref];
+        ch[best] = left_of(open);
+        ch[n++] = right_of(open);
+      }
+      DevNodeW w;
+      for (int i = 0; i < 4; i++) {
+        if (i >= n) {
+          w.px[i] = w.py[i] = w.pz[i] = 0;
+          w.child[i] = kRefNone;
+          continue;
+        }
+        w.px[i] = (uint32_t)ch[i].mn[0] | ((uint32_t)ch[i].mx[0] << 16);
+        w.py[i] = (uint32_t)ch[i].mn[1] | ((uint32_t)ch[i].mx[1] << 16);
+        w.pz[i] = (uint32_t)ch[i].mn[2] | ((uint32_t)ch[i].mx[2] << 16);
+        if (ch[i].ref & kRefLeaf) {
+          w.child[i] = ch[i].ref;
+        } else {
+          w.child[i] = (uint32_t)nodes_w.size();
+          todo.push_back({ch[i].ref, (uint32_t)nodes_w.size()});
+          nodes_w.emplace_back();
+        }
+      }
+      nodes_w[it.wide] = w;
+    }
+    // stack entries a lane can need below a node: all but one of its children pushed, then the deepest child
+    // (children are stored after their parent, so one backward pass does it)
+    std::vector<int32_t> need(nodes_w.size(), 0);
+    for (size_t i = nodes_w.size(); i-- > 0;) {
+      int32_t deepest = 0, k = 0;
+      for (int c = 0; c < 4; c++) {
+        uint32_t r = nodes_w[i].child[c];
+        if (r == kRefNone) continue;
+        k++;
+        if (!(r & kRefLeaf)) deepest = std::max(deepest, need[r]);
+      }
+      need[i] = deepest + k - 1;
+    }
+    stack_depth_w = std::max(need[0], 1);
+    if (verbose) fprintf(stderr, "rt_hip upload: %zu wide nodes for %d binary ones, stack need %d\n", nodes_w.size(), n_internal, stack_depth_w);
+    if (stack_depth_w > kMaxStackDepth + kWideLdsLevels) nodes_w.clear();
+  }
   std::vector<DevTriangle> tris((size_t)s->n_triangles);
   std::vector<DevTriShade> tri_shade((size_t)s->n_triangles);
   std::vector<DevQuad> quads((size_t)s->n_quads);
@@ -1973,6 +2083,10 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   if (!nodes_q.empty()) step(dev_upload(h, &h->dev.nodes_q, nodes_q));
   h->dev.nodes_d = nullptr;
   if (!nodes_d.empty()) step(dev_upload(h, &h->dev.nodes_d, nodes_d));
+  h->dev.nodes_w = nullptr;
+  if (!nodes_w.empty()) step(dev_upload(h, &h->dev.nodes_w, nodes_w));
+  h->dev.root_w = nodes_w.empty() ? ref_of_node(0) : 0u;
+  h->dev.stack_depth_w = stack_depth_w;
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
   step(dev_upload(h, &h->dev.triangles, tris));
   step(dev_upload(h, &h->dev.tri_shade, tri_shade));
