@@ -185,11 +185,15 @@ RT_DEV uint64_t splitmix64_mix(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
   return z ^ (z >> 31);
 }
-RT_DEV uint64_t rng_seed_path(uint64_t pixel_index, uint64_t batch, uint64_t sample, uint64_t seed) {
-  uint64_t k = splitmix64_mix(pixel_index + 0x9e3779b97f4a7c15ULL);
-  k = splitmix64_mix(k ^ (batch * 0xd1342543de82ef95ULL + 0x632be59bd9b4e019ULL));
+// the stream's key is mixed from the pixel first: that part is the same for every batch and sample of the pixel
+RT_DEV uint64_t rng_seed_pixel(uint64_t pixel_index) { return splitmix64_mix(pixel_index + 0x9e3779b97f4a7c15ULL); }
+RT_DEV uint64_t rng_seed_path_of(uint64_t pixel_key, uint64_t batch, uint64_t sample, uint64_t seed) {
+  uint64_t k = splitmix64_mix(pixel_key ^ (batch * 0xd1342543de82ef95ULL + 0x632be59bd9b4e019ULL));
   k = splitmix64_mix(k ^ (sample * 0xaf251af3b0f025b5ULL + 0x9e3779b97f4a7c15ULL));
   return splitmix64_mix(k ^ seed);
+}
+RT_DEV uint64_t rng_seed_path(uint64_t pixel_index, uint64_t batch, uint64_t sample, uint64_t seed) {
+  return rng_seed_path_of(rng_seed_pixel(pixel_index), batch, sample, seed);
 }
 RT_DEV uint64_t rng_next_u64(uint64_t &s) {
   s += 0x9e3779b97f4a7c15ULL;

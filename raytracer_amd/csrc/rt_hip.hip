@@ -163,53 +163,66 @@ __device__ __forceinline__ uint32_t xcd_logical_block(uint32_t b, uint32_t nbloc
 }
 
 // ================================================================== generate
-// One lane per (active pixel slot, batch g of the group, sample i); the path
-// id is (slot * G + g) * S + i, so the samples of one batch of one pixel are
-// adjacent: coherent primary rays, and paths that end at the same bounce store
-// neighbouring result records.  The Sobol index restarts with every
-// batch (integrator.rs:285), so the filter weight of sample i of a pixel is the
-// same in every batch: it is stored once, by batch 0, as weights[i * n_pix + p].
+// The path id is (slot * G + g) * S + i, so the samples of one batch of one pixel are adjacent: coherent primary
+// rays, and paths that end at the same bounce store neighbouring result records.  The Sobol index restarts with
+// every batch (integrator.rs:285): sample i of a pixel has the same offset, filter weight and -- without a lens --
+// the same direction in every batch.  So one lane takes (active pixel slot, sample i), does that arithmetic once
+// and then writes the G paths of the round's batches, which differ in their random-number stream only (and, with a
+// lens, in the origin it draws).  The weight is stored once, by batch 0, as weights[i * n_pix + p].
+// Neighbouring lanes write runs of S entries G * S apart; the runs of consecutive batches are adjacent, so the
+// lines they share are completed in the cache by the next trip of the same lanes.
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
                                                    int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
   int64_t n = (int64_t)n_slots * G * rp.S;
   const uint32_t share = region_share(n);
   if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
-  uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
-  for (int64_t j = (int64_t)lb * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-    // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit divisions, not 64-bit ones
-    uint32_t j32 = (uint32_t)j, sg = j32 / (uint32_t)rp.S;
-    int32_t i = (int32_t)(j32 - sg * (uint32_t)rp.S);
-    int32_t slot = (int32_t)(sg / (uint32_t)G), g = (int32_t)(sg - (uint32_t)slot * (uint32_t)G);
-    uint32_t p = pixel_of_key(rp, active[slot]);
-    int32_t x = (int32_t)(p % (uint32_t)rp.width);
-    int32_t y = image_row(rp, p / (uint32_t)rp.width);
+  const uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
+  // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit arithmetic throughout
+  const uint32_t S = (uint32_t)rp.S, n_si = (uint32_t)n_slots * S;
+  const bool lens = !(sc.camera.defocus_angle <= 0.0);
+  const d3 center = ld3(sc.camera.camera_center);
+  for (uint32_t k = lb * blockDim.x + threadIdx.x; k < n_si; k += gridDim.x * blockDim.x) {
+    const uint32_t slot = k / S, i = k - slot * S;
+    const uint32_t p = pixel_of_key(rp, active[slot]);
+    const int32_t x = (int32_t)(p % (uint32_t)rp.width);
+    const int32_t y = image_row(rp, p / (uint32_t)rp.width);
     // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
-    uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
-    double sx = ((double)sobol_sample((uint32_t)i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
-    double sy = ((double)sobol_sample((uint32_t)i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
-    double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
-    double w = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
-    uint64_t rng = rng_seed_path((uint64_t)y * (uint64_t)rp.width + (uint64_t)x, (uint64_t)(batch0 + g), (uint64_t)i, rp.seed);
+    const uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
+    const double sx = ((double)sobol_sample(i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
+    const double sy = ((double)sobol_sample(i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
+    if (batch0 == 0) {
+      const double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
+      weights[(size_t)i * (size_t)rp.n_pix + p] = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
+    }
     // camera.rs:95-120
-    d3 center = ld3(sc.camera.camera_center);
-    d3 origin = center;
-    if (!(sc.camera.defocus_angle <= 0.0)) {
-      d3 pd = random_in_unit_disk(rng);
-      origin = center + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
+    const d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
+    const d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
+    d3 dir = normalized(pixel_sample - center);
+    const uint64_t pixel_key = rng_seed_pixel((uint64_t)y * (uint64_t)rp.width + (uint64_t)x);
+    // entry of the path of batch g: j = (slot * G + g) * S + i, region by region (region_place)
+    uint32_t j = slot * (uint32_t)G * S + i;
+    uint32_t r = j / share, off = j - r * share;
+    for (int32_t g = 0; g < G; g++) {
+      uint64_t rng = rng_seed_path_of(pixel_key, (uint64_t)(batch0 + g), (uint64_t)i, rp.seed);
+      const uint32_t e = r * q.cap + off;
+      // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
+      if (lens) {
+        d3 pd = random_in_unit_disk(rng);
+        d3 origin = center + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
+        dir = normalized(pixel_sample - origin);
+        q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+      }
+      q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
+      // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
+      q.rng[e] = rng;
+      q.pid[e] = j;
+      j += S;
+      off += S;
+      if (off >= share) {  // S <= share: at most one region further
+        off -= share;
+        r++;
+      }
     }
-    d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
-    d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
-    d3 dir = normalized(pixel_sample - origin);
-    uint32_t e = region_place(j, share, q.cap);
-    // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
-    if (!(sc.camera.defocus_angle <= 0.0)) {
-      q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
-    }
-    q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
-    // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
-    q.rng[e] = rng;
-    q.pid[e] = (uint32_t)j;
-    if (batch0 + g == 0) weights[(size_t)i * (size_t)rp.n_pix + p] = w;
   }
 }
 
@@ -2285,13 +2298,12 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       int32_t ns = (int32_t)std::min<uint32_t>(chunk_slots, n_active - base);
       int64_t np = (int64_t)ns * S * G;
       HIP_TRY(hipMemsetAsync(qcounts, 0, (n_counters - kCounterStride) * sizeof(uint32_t), st));
-      int g = grid_for(np, block, max_blocks);
       // k_shade: a whole number of workgroups per region, and many more of them than fit the
       // chip at once -- short workgroups even out the uneven cost of the material branches
       static const int shade_blocks = getenv("RT_HIP_SHADE_BLOCKS") ? std::max((int)kRegions, atoi(getenv("RT_HIP_SHADE_BLOCKS")) / (int)kRegions * (int)kRegions) : 256 * 64;
       int g_shade = (int)std::min<int64_t>(shade_blocks, (np / block / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
-      hipLaunchKernelGGL(k_generate, dim3(g), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for((int64_t)ns * S, block, max_blocks)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
         HIP_TRY(mark_begin(0, k));
