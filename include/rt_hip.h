@@ -201,7 +201,12 @@ typedef struct RtConfig {
   int32_t row_first;
   int32_t row_stride;
   int32_t row_block;
-  int32_t reserved;
+  /* Device working memory this render may take for its path queues, hit buffers and per-path results, in MiB
+   * (no counterpart in the reference, whose working state is the call stack).  0: up to half of the device
+   * memory that is free when the render starts, at most 2^29 paths in flight (about 125 GB).  A smaller
+   * budget means more, smaller rounds -- the image does not change.  The handle keeps one working block,
+   * sized by its largest render, until rt_hip_scene_free. */
+  int32_t work_mib;
 } RtConfig;
 
 /* Output buffers, caller-allocated, library-filled.  n_rows = number of rows

@@ -100,7 +100,7 @@ class RtConfig(C.Structure):
         ("rng_mode", C.c_int32), ("flags", C.c_int32),
         ("seed", C.c_uint64),
         ("row_first", C.c_int32), ("row_stride", C.c_int32),
-        ("row_block", C.c_int32), ("reserved", C.c_int32),
+        ("row_block", C.c_int32), ("work_mib", C.c_int32),
     ]
 
     def copy(self):

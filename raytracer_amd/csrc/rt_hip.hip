@@ -62,6 +62,13 @@ static int fail(int code, const std::string &msg) {
     }                                                                                                \
   } while (0)
 
+// After a kernel launch: a launch that was refused (too much LDS, bad grid) is reported at once, by the kernel's name.
+#define LAUNCHED(name)                                                                               \
+  do {                                                                                               \
+    hipError_t e_ = hipGetLastError();                                                               \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string("launch of " name ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
 constexpr int32_t kFlagTimeKernels = RT_FLAG_TIME_KERNELS;
 constexpr int32_t kFlagCountVisits = RT_FLAG_COUNT_VISITS;
 constexpr int32_t kFlagEarlyTerminate = RT_FLAG_EARLY_TERMINATE;
@@ -166,59 +173,110 @@ __device__ __forceinline__ uint32_t xcd_logical_block(uint32_t b, uint32_t nbloc
 // The path id is (slot * G + g) * S + i, so the samples of one batch of one pixel are adjacent: coherent primary
 // rays, and paths that end at the same bounce store neighbouring result records.  The Sobol index restarts with
 // every batch (integrator.rs:285): sample i of a pixel has the same offset, filter weight and -- without a lens --
-// the same direction in every batch.  So one lane takes (active pixel slot, sample i), does that arithmetic once
-// and then writes the G paths of the round's batches, which differ in their random-number stream only (and, with a
-// lens, in the origin it draws).  The weight is stored once, by batch 0, as weights[i * n_pix + p].
-// Neighbouring lanes write runs of S entries G * S apart; the runs of consecutive batches are adjacent, so the
-// lines they share are completed in the cache by the next trip of the same lanes.
-__global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
+// the same direction in every batch; the paths of its G batches in a round differ in their random-number stream only
+// (and, with a lens, in the origin it draws).  The weight is stored once, by batch 0, as weights[i * n_pix + p].
+struct GenSample {  // what the batches of one (pixel, sample i) share
+  d3 pixel_sample, dir;
+  uint64_t pixel_key;
+};
+RT_DEV GenSample generate_sample(const DevScene &sc, const RenderParams &rp, const uint32_t *active, uint32_t slot, uint32_t i, int32_t batch0, double *weights) {
+  const uint32_t p = pixel_of_key(rp, active[slot]);
+  const int32_t x = (int32_t)(p % (uint32_t)rp.width);
+  const int32_t y = image_row(rp, p / (uint32_t)rp.width);
+  // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
+  const uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
+  const double sx = ((double)sobol_sample(i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
+  const double sy = ((double)sobol_sample(i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
+  if (batch0 == 0) {
+    const double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
+    weights[(size_t)i * (size_t)rp.n_pix + p] = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
+  }
+  // camera.rs:95-120
+  const d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
+  GenSample gs;
+  gs.pixel_sample = pixel_loc + D3(sx, sy, 0.);
+  gs.dir = normalized(gs.pixel_sample - ld3(sc.camera.camera_center));
+  gs.pixel_key = rng_seed_pixel((uint64_t)y * (uint64_t)rp.width + (uint64_t)x);
+  return gs;
+}
+RT_DEV void generate_store(const DevScene &sc, const RenderParams &rp, const GenSample &gs, uint32_t batch, uint32_t i, uint32_t j, uint32_t e, const PathQueue &q) {
+  uint64_t rng = rng_seed_path_of(gs.pixel_key, (uint64_t)batch, (uint64_t)i, rp.seed);
+  d3 dir = gs.dir;
+  // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
+  if (!(sc.camera.defocus_angle <= 0.0)) {
+    d3 pd = random_in_unit_disk(rng);
+    d3 origin = ld3(sc.camera.camera_center) + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
+    dir = normalized(gs.pixel_sample - origin);
+    q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+  }
+  q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
+  // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
+  q.rng[e] = rng;
+  q.pid[e] = j;
+}
+// A workgroup takes `spb` consecutive pixel slots: its first spb * S lanes do the shared arithmetic of one
+// (slot, sample) each and leave it in LDS, then all lanes write the slots' spb * G * S paths, which are contiguous
+// in the queue, in order: whole lines per store instruction.
+constexpr int kGenMaxShared = 512;  // (slot, sample) pairs per workgroup; S above it takes k_generate_strided
+__global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots, int32_t spb,
                                                    int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
-  int64_t n = (int64_t)n_slots * G * rp.S;
+  __shared__ double sh_f64[3][kGenMaxShared];
+  __shared__ uint64_t sh_key[kGenMaxShared];
+  // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit arithmetic throughout
+  const int64_t n = (int64_t)n_slots * G * rp.S;
+  const uint32_t share = region_share(n);
+  if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
+  const uint32_t S = (uint32_t)rp.S, GS = (uint32_t)G * S;
+  const bool lens = !(sc.camera.defocus_angle <= 0.0);
+  const uint32_t n_chunks = ((uint32_t)n_slots + (uint32_t)spb - 1u) / (uint32_t)spb;
+  for (uint32_t chunk = xcd_logical_block(blockIdx.x, gridDim.x); chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t slot0 = chunk * (uint32_t)spb, slots = min((uint32_t)spb, (uint32_t)n_slots - slot0);
+    __syncthreads();  // the previous chunk's readers are done
+    for (uint32_t k = threadIdx.x; k < slots * S; k += blockDim.x) {
+      const uint32_t sl = k / S, i = k - sl * S;
+      GenSample gs = generate_sample(sc, rp, active, slot0 + sl, i, batch0, weights);
+      const d3 v = lens ? gs.pixel_sample : gs.dir;
+      sh_f64[0][k] = v.x; sh_f64[1][k] = v.y; sh_f64[2][k] = v.z;
+      sh_key[k] = gs.pixel_key;
+    }
+    __syncthreads();
+    const uint32_t j0 = slot0 * GS, count = slots * GS;
+    const uint32_t r0 = j0 / share;
+    const bool one_boundary = count <= share;  // the chunk's paths lie in region r0 and at most the next one
+    for (uint32_t idx = threadIdx.x; idx < count; idx += blockDim.x) {
+      const uint32_t sl = idx / GS, rem = idx - sl * GS, g = rem / S, i = rem - g * S, k = sl * S + i;
+      const uint32_t j = j0 + idx;
+      uint32_t r = r0;
+      if (one_boundary) r += (j >= (r0 + 1u) * share) ? 1u : 0u;
+      else r = j / share;
+      const uint32_t e = r * q.cap + (j - r * share);
+      GenSample gs;
+      gs.pixel_sample = gs.dir = D3(sh_f64[0][k], sh_f64[1][k], sh_f64[2][k]);
+      gs.pixel_key = sh_key[k];
+      generate_store(sc, rp, gs, (uint32_t)batch0 + g, i, j, e, q);
+    }
+  }
+}
+// The same for batches of more than kGenMaxShared samples: one lane takes (active pixel slot, sample i), does the shared
+// arithmetic once and writes the G paths of the round's batches (runs of S entries, G * S apart).
+__global__ void __launch_bounds__(256) k_generate_strided(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
+                                                           int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
+  const int64_t n = (int64_t)n_slots * G * rp.S;
   const uint32_t share = region_share(n);
   if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
   const uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
-  // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit arithmetic throughout
   const uint32_t S = (uint32_t)rp.S, n_si = (uint32_t)n_slots * S;
-  const bool lens = !(sc.camera.defocus_angle <= 0.0);
-  const d3 center = ld3(sc.camera.camera_center);
   for (uint32_t k = lb * blockDim.x + threadIdx.x; k < n_si; k += gridDim.x * blockDim.x) {
     const uint32_t slot = k / S, i = k - slot * S;
-    const uint32_t p = pixel_of_key(rp, active[slot]);
-    const int32_t x = (int32_t)(p % (uint32_t)rp.width);
-    const int32_t y = image_row(rp, p / (uint32_t)rp.width);
-    // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
-    const uint32_t sobol_seed = (uint32_t)((uint64_t)x * (uint64_t)y);
-    const double sx = ((double)sobol_sample(i, 0, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
-    const double sy = ((double)sobol_sample(i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
-    if (batch0 == 0) {
-      const double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
-      weights[(size_t)i * (size_t)rp.n_pix + p] = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
-    }
-    // camera.rs:95-120
-    const d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
-    const d3 pixel_sample = pixel_loc + D3(sx, sy, 0.);
-    d3 dir = normalized(pixel_sample - center);
-    const uint64_t pixel_key = rng_seed_pixel((uint64_t)y * (uint64_t)rp.width + (uint64_t)x);
+    const GenSample gs = generate_sample(sc, rp, active, slot, i, batch0, weights);
     // entry of the path of batch g: j = (slot * G + g) * S + i, region by region (region_place)
     uint32_t j = slot * (uint32_t)G * S + i;
     uint32_t r = j / share, off = j - r * share;
     for (int32_t g = 0; g < G; g++) {
-      uint64_t rng = rng_seed_path_of(pixel_key, (uint64_t)(batch0 + g), (uint64_t)i, rp.seed);
-      const uint32_t e = r * q.cap + off;
-      // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
-      if (lens) {
-        d3 pd = random_in_unit_disk(rng);
-        d3 origin = center + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
-        dir = normalized(pixel_sample - origin);
-        q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
-      }
-      q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
-      // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
-      q.rng[e] = rng;
-      q.pid[e] = j;
+      generate_store(sc, rp, gs, (uint32_t)(batch0 + g), i, j, r * q.cap + off, q);
       j += S;
       off += S;
-      if (off >= share) {  // S <= share: at most one region further
+      while (off >= share) {
         off -= share;
         r++;
       }
@@ -1347,6 +1405,7 @@ int check_config(const RtConfig *cfg) {
   if (cfg->row_stride <= 0 || cfg->row_first < 0 || cfg->row_block < 0 || (int64_t)cfg->row_first * row_block_of(cfg) >= cfg->img_height)
     return fail(RT_ERR_BAD_ARG, "row shard out of range");
   if (!(cfg->pixel_radius > 0.0) || !(cfg->gamma_correction > 0.0)) return fail(RT_ERR_BAD_ARG, "pixel_radius and gamma_correction must be > 0");
+  if (cfg->work_mib < 0) return fail(RT_ERR_BAD_ARG, "work_mib must be >= 0");
   if (cfg->rng_mode != RT_RNG_CTR)
     return fail(RT_ERR_UNSUPPORTED, "the device path implements RT_RNG_CTR only (RT_RNG_REF is serial per image row)");
   int64_t n_pix = (int64_t)shard_rows(cfg) * cfg->img_width;
@@ -2158,6 +2217,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     for (const ArenaBlock &blk : h->arena) held += blk.size;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_paths = std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2) / bytes_per_path);
   }
+  if (cfg->work_mib > 0) max_paths = std::min<int64_t>(max_paths, ((int64_t)cfg->work_mib << 20) / bytes_per_path);
   if (const char *env = getenv("RT_HIP_MAX_PATHS")) {
     long long v = atoll(env);
     if (v >= 1) max_paths = v;
@@ -2251,6 +2311,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   const int block = 256;
   const int max_blocks = 256 * 8;  // 256 CUs x 8 resident workgroups
   hipLaunchKernelGGL(k_all_keys, dim3(grid_for(n_pix, block, max_blocks)), dim3(block), 0, st, rp, active[1], (uint32_t)n_pix);
+  LAUNCHED("k_all_keys");
   HIP_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, active[1], active[0], (int)n_pix, 0, sort_bits, st));
 
   struct TimedLaunch {
@@ -2303,17 +2364,25 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       static const int shade_blocks = getenv("RT_HIP_SHADE_BLOCKS") ? std::max((int)kRegions, atoi(getenv("RT_HIP_SHADE_BLOCKS")) / (int)kRegions * (int)kRegions) : 256 * 64;
       int g_shade = (int)std::min<int64_t>(shade_blocks, (np / block / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
-      hipLaunchKernelGGL(k_generate, dim3(grid_for((int64_t)ns * S, block, max_blocks)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
+      if (S <= kGenMaxShared) {
+        const int spb = std::max(1, std::min(block, kGenMaxShared) / S);  // pixel slots per workgroup: about one (slot, sample) per lane
+        hipLaunchKernelGGL(k_generate, dim3(grid_for(((int64_t)ns + spb - 1) / spb, 1, 1 << 20)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, spb, b, G, q[0], weights, qcounts);
+      } else {
+        hipLaunchKernelGGL(k_generate_strided, dim3(grid_for((int64_t)ns * S, block, max_blocks)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
+      }
+      LAUNCHED("k_generate");
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
         HIP_TRY(mark_begin(0, k));
         launch_extend(h->dev, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
                       totals + RT_MAX_DEPTH_STATS + 1);
+        LAUNCHED("k_extend");
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1, k));
         static_assert(block == 256, "k_shade sorts per workgroup of four waves");
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
                            results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
+        LAUNCHED("k_shade");
         HIP_TRY(mark_end());
       }
       HIP_TRY(mark_begin(2));
@@ -2322,6 +2391,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       }
       hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ns, block, max_blocks)), dim3(block), 0, st, rp, active[cur] + base, ns, b, G, results, weights,
                          sums, hist, active[cur ^ 1], counters, po, qcounts, totals);
+      LAUNCHED("k_accumulate");
       HIP_TRY(mark_end());
     }
     HIP_TRY(hipGetLastError());
@@ -2437,7 +2507,9 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
   launch_extend(h->dev, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
+  LAUNCHED("k_hits_to_elements");
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(prim_id, d_id, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -2473,6 +2545,7 @@ static int primary_hits_impl(RtSceneHandle *h, const RtConfig *cfg, int32_t *pri
   rc = alloc_ray_queue(h, sc, n, &q, &d_count);
   if (rc != RT_OK) return rc;
   hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, rp, q, d_count);
+  LAUNCHED("k_primary_rays");
   return trace_queue(h, sc, n, q, d_count, cfg->flags, prim_id, t);
 }
 
@@ -2492,6 +2565,7 @@ static int trace_rays_impl(RtSceneHandle *h, int64_t n, const double *origins, c
   int rc = alloc_ray_queue(h, sc, n, &q, &d_count);
   if (rc != RT_OK) return rc;
   hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_o, d_d, q, d_count);
+  LAUNCHED("k_caller_rays");
   return trace_queue(h, sc, n, q, d_count, 0, prim_id, t);
 }
 
@@ -2557,9 +2631,12 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   // the array keeps the last call's contents: the counters must start at zero
   HIP_TRY(hipMemsetAsync(d_counts, 0, kNoAllocCounterBytes, h->stream));
   hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_origins, d_directions, q, d_counts);
+  LAUNCHED("k_caller_rays");
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
   launch_extend(h->dev, walk_mode(h, 0), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, n, q.cap, hits, d_prim_id, d_t);
+  LAUNCHED("k_hits_to_elements");
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return RT_OK;

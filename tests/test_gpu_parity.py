@@ -378,6 +378,19 @@ def test_odd_image_shapes_match_the_oracle(width, height, stride):
         assert st_g.samples == st_o.samples
 
 
+@pytest.mark.parametrize("batch,defocus", [(1, 0.0), (3, 0.0), (300, 0.0), (700, 0.0), (40, 0.6)])
+def test_odd_batch_sizes_match_the_oracle(batch, defocus):
+    """Batches of one sample, of more samples than a workgroup has lanes, of more than the ray generator shares
+    through LDS (it then takes its strided form); a lens (the origin is drawn per path)."""
+    ri = c1(width=9, height=7, batch=batch, max_batches=5, min_batches=1, defocus=defocus)
+    cfg = ri.config.copy()
+    out_g, st_g = ri.resident(0).render(cfg)
+    out_o, st_o = oracle.render(ri.scene, cfg, 4)
+    assert np.array_equal(out_g["samples"], out_o["samples"])
+    assert_image_parity(out_g, out_o, f"batch {batch}", ri.resident(0), cfg)
+    assert st_g.samples == st_o.samples
+
+
 def test_early_termination_flag_does_not_change_pixels():
     ri = c1(width=32, height=32, batch=16)
     cfg = ri.config.copy()
@@ -576,6 +589,32 @@ def test_working_memory_of_a_handle_is_what_its_largest_render_needed():
     g1 = free_bytes()
     assert f0 - f2 <= (g0 - g1) + (4 << 20), (f0 - f2, g0 - g1)
     assert np.array_equal(a["linear"], b["linear"]) and np.array_equal(s["linear"], s2["linear"]) and np.array_equal(s["linear"], a["linear"][3::8])
+
+
+def test_working_memory_budget_changes_rounds_not_pixels():
+    """RtConfig.work_mib caps the device memory a render takes for its paths: more, smaller rounds, same image."""
+    torch = pytest.importorskip("torch")
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    free = c1(width=512, height=512, batch=16, max_batches=4, min_batches=1)
+    tight = c1(width=512, height=512, batch=16, max_batches=4, min_batches=1)
+    cfg_t = tight.config.copy()
+    cfg_t.work_mib = 64
+    f0 = free_bytes()
+    a, st_a = tight.resident(0).render(cfg_t)
+    f1 = free_bytes()
+    b, st_b = free.resident(0).render(free.config.copy())
+    f2 = free_bytes()
+    assert np.array_equal(a["linear"], b["linear"]) and np.array_equal(a["pixels"], b["pixels"]) and st_a.rays == st_b.rays
+    assert 0 < f0 - f1 <= (64 + 128) << 20, f0 - f1  # the paths' 64 MiB + sums, weights, history and outputs of 262 144 pixels (~80 MB)
+    assert f1 - f2 > 2 * (f0 - f1)                   # the unlimited render took what the whole first round needs
+    bad = tight.config.copy()
+    bad.work_mib = -1
+    with pytest.raises(abi.RtError):
+        tight.resident(0).render(bad)
 
 
 @pytest.mark.parametrize("block,world", [(8, 3), (2, 4), (8, 8), (5, 2)])
