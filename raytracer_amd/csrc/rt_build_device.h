@@ -432,6 +432,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   hipLaunchKernelGGL(k_emit_prims, dim3(grid), dim3(block), 0, st, n, ids, d_tri_pos, d_slot, d_elements, d_tris, d_quads, d_spheres, o_tris, o_shade,
                      o_quads, o_spheres, d_leaf_ref);
   h->dev.triangles = o_tris;
+  h->dev.tri_stride = (uint32_t)sizeof(DevTriangle);
   h->dev.tri_shade = o_shade;
   h->dev.quads = o_quads;
   h->dev.spheres = o_spheres;
@@ -552,7 +553,7 @@ static int scene_download_tree_impl(RtSceneHandle *h, RtNode *nodes, int32_t cap
   HIP_TRY(hipSetDevice(h->device));
   auto element_of_ref = [&](uint32_t ref, int32_t *element) -> int {
     uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask, e = 0;
-    const char *src = kind == RT_PRIM_TRIANGLE ? (const char *)&h->dev.triangles[idx].element
+    const char *src = kind == RT_PRIM_TRIANGLE ? (const char *)&tri_record(h->dev, idx)->element
                       : kind == RT_PRIM_QUAD   ? (const char *)&h->dev.quads[idx].element
                                                : (const char *)&h->dev.spheres[idx].element;
     HIP_TRY(hipMemcpy(&e, src, sizeof e, hipMemcpyDeviceToHost));
@@ -581,7 +582,7 @@ static int scene_download_tree_impl(RtSceneHandle *h, RtNode *nodes, int32_t cap
       }
   if (any[RT_PRIM_TRIANGLE]) {
     tris.resize((size_t)max_idx[RT_PRIM_TRIANGLE] + 1);
-    HIP_TRY(hipMemcpy(tris.data(), h->dev.triangles, tris.size() * sizeof(DevTriangle), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(tris.data(), sizeof(DevTriangle), h->dev.triangles, h->dev.tri_stride, sizeof(DevTriangle), tris.size(), hipMemcpyDeviceToHost));
   }
   if (any[RT_PRIM_QUAD]) {
     quads.resize((size_t)max_idx[RT_PRIM_QUAD] + 1);

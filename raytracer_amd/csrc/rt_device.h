@@ -130,7 +130,8 @@ struct DevScene {
   uint32_t root_w;          // ref of the wide root (a leaf ref when the tree is a single leaf)
   int32_t stack_depth_w;    // stack entries a lane can need on the wide nodes
   double grid_min[3], grid_step[3];  // grid value q on axis a stands for grid_min[a] + q * grid_step[a]
-  const DevTriangle *triangles;
+  const DevTriangle *triangles;  // record i starts i * tri_stride bytes in: see tri_record
+  uint32_t tri_stride;           // 80, or 128 (one record per line, none across two) when the records do not fit the caches
   const DevTriShade *tri_shade;
   const DevQuad *quads;
   const DevSphere *spheres;
@@ -153,6 +154,10 @@ struct DevScene {
   int32_t n_danger;
   RtCamera camera;
 };
+
+__host__ __device__ inline const DevTriangle *tri_record(const DevScene &sc, uint32_t idx) {
+  return reinterpret_cast<const DevTriangle *>(reinterpret_cast<const char *>(sc.triangles) + (size_t)idx * sc.tri_stride);
+}
 
 // ----------------------------------------------------------------- vec3
 struct d3 {
@@ -838,7 +843,7 @@ RT_DEV void trav_defer_leaf(Traversal &tv, const uint32_t *stack, uint32_t *leaf
 // accepted before -- in whatever order this traversal happened to reach them.
 RT_DEV uint32_t leaf_rank(const DevScene &sc, uint32_t leaf) {
   uint32_t kind = (leaf >> kRefKindShift) & 3u, idx = leaf & kRefIndexMask;
-  if (kind == RT_PRIM_TRIANGLE) return sc.triangles[idx].rank;
+  if (kind == RT_PRIM_TRIANGLE) return tri_record(sc, idx)->rank;
   if (kind == RT_PRIM_QUAD) return sc.quads[idx].rank;
   return sc.spheres[idx].rank;
 }
@@ -861,7 +866,7 @@ RT_DEV void trav_test_leaf(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32
   double t;
   bool ok;
   if (kind == RT_PRIM_TRIANGLE) {
-    const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[idx]);
+    const double2 *p = reinterpret_cast<const double2 *>(tri_record(sc, idx));
     double2 a = p[0], b = p[1], c = p[2], dd = p[3], e = p[4];
     ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);
   } else if (kind == RT_PRIM_QUAD) {
@@ -893,7 +898,7 @@ RT_DEV void trav_accept_fast(const DevScene &sc, Traversal &tv, uint32_t leaf, b
 }
 RT_DEV void trav_test_triangle_fast(const DevScene &sc, d3 o, d3 d, Traversal &tv, uint32_t leaf) {
   Ray r = {o, d, D3(0, 0, 0)};
-  const double2 *p = reinterpret_cast<const double2 *>(&sc.triangles[leaf & kRefIndexMask]);
+  const double2 *p = reinterpret_cast<const double2 *>(tri_record(sc, leaf & kRefIndexMask));
   double2 a = p[0], b = p[1], c = p[2], dd = p[3], e = p[4];
   double t;
   bool ok = triangle_hit(D3(a.x, a.y, b.x), D3(b.y, c.x, c.y), D3(dd.x, dd.y, e.x), r, kTMin, tv.best.t, t);

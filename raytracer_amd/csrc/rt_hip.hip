@@ -1201,7 +1201,7 @@ __global__ void k_all_keys(RenderParams rp, uint32_t *a, uint32_t n) {
 RT_DEV int32_t element_of(const DevScene &sc, uint32_t ref) {
   if (ref == kRefNone) return -1;
   uint32_t kind = (ref >> kRefKindShift) & 3u, idx = ref & kRefIndexMask;
-  if (kind == RT_PRIM_TRIANGLE) return (int32_t)sc.triangles[idx].element;
+  if (kind == RT_PRIM_TRIANGLE) return (int32_t)tri_record(sc, idx)->element;
   if (kind == RT_PRIM_QUAD) return (int32_t)sc.quads[idx].element;
   return (int32_t)sc.spheres[idx].element;
 }
@@ -2160,7 +2160,26 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   h->dev.root_w = nodes_w.empty() ? ref_of_node(0) : 0u;
   h->dev.stack_depth_w = stack_depth_w;
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
-  step(dev_upload(h, &h->dev.triangles, tris));
+  // Triangle records that do not fit the caches are fetched line by line from HBM: at 80 bytes apart every second
+  // record lies across two 128-byte lines, at 128 bytes apart none does.
+  const char *pad_env = getenv("RT_HIP_TRI_PAD");
+  const bool padded = pad_env ? atoi(pad_env) != 0 : tris.size() * sizeof(DevTriangle) > ((size_t)256 << 20);
+  h->dev.tri_stride = padded ? 128u : (uint32_t)sizeof(DevTriangle);
+  if (padded) {
+    struct alignas(128) Padded {
+      DevTriangle t;
+    };
+    static_assert(sizeof(Padded) == 128, "one record per line");
+    std::vector<Padded> wide_tris(tris.size());
+    parallel_for(tris.size(), [&](size_t begin, size_t end) {
+      for (size_t i = begin; i < end; i++) wide_tris[i].t = tris[i];
+    });
+    const Padded *dst = nullptr;
+    step(dev_upload(h, &dst, wide_tris));
+    h->dev.triangles = reinterpret_cast<const DevTriangle *>(dst);
+  } else {
+    step(dev_upload(h, &h->dev.triangles, tris));
+  }
   step(dev_upload(h, &h->dev.tri_shade, tri_shade));
   step(dev_upload(h, &h->dev.quads, quads));
   step(dev_upload(h, &h->dev.spheres, spheres));
