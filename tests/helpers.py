@@ -37,7 +37,7 @@ def random_rays(n, seed=0):
 
 
 # ------------------------------------------------------------ the reference's own input files
-# Data the reference ships (input/scene_teapot.json, input/config.json, input/obj/teapot.obj,
+# Data the reference ships (input/scene.json, input/scene_teapot.json, input/config.json, input/obj/teapot.obj,
 # input/obj/diamond.obj), kept under tests/golden/ref_inputs as inputs for the loader and the renders.
 REF_INPUTS = os.path.join(GOLDEN, "ref_inputs")
 
@@ -60,6 +60,29 @@ def teapot_scene(width, height, batch, max_batches, min_batches):
     cfg = ref_config(img_width=float(width), img_height=float(height), sample_batch_size=int(batch),
                      max_sample_batches=int(max_batches), min_sample_batches=int(min_batches))
     return RenderIntegrator.new(scene, cfg, base_dir=REF_INPUTS).prepare()
+
+
+def readme_scene(directory, n_triangles, width, height, batch, max_batches, min_batches):
+    """input/scene.json, the scene of the reference's README render: a dragon from input/obj/dragon.obj (scaled 22x, rotated,
+    moved) + metal box + walls + quad light (attractor).  The reference does not distribute dragon.obj: a generated mesh
+    of `n_triangles` is written under that name (scaled to the dragon's size: unit-sized coordinates), everything else is
+    the reference's file as it stands, with input/config.json resized."""
+    import json
+    import shutil
+    base = os.path.join(directory, f"readme_{n_triangles}")
+    os.makedirs(os.path.join(base, "input", "obj"), exist_ok=True)
+    obj = os.path.join(base, "input", "obj", "dragon.obj")
+    if not os.path.exists(obj):
+        v, f = scenes.knot_mesh(n_triangles)
+        v = (v - v.mean(axis=0)) / np.abs(v - v.mean(axis=0)).max() * 5.0 + np.array([0.0, 5.0, 0.0])  # about 10 units across, standing on y = 0
+        scenes.write_obj(obj + ".tmp", v, f)
+        os.replace(obj + ".tmp", obj)
+    shutil.copy(os.path.join(REF_INPUTS, "scene.json"), os.path.join(base, "scene.json"))
+    with open(os.path.join(base, "scene.json")) as f:
+        scene = json.load(f)
+    cfg = ref_config(img_width=float(width), img_height=float(height), sample_batch_size=int(batch),
+                     max_sample_batches=int(max_batches), min_sample_batches=int(min_batches))
+    return RenderIntegrator.new(scene, cfg, base_dir=base).prepare()
 
 
 # ------------------------------------------------------------------------------ image gates

@@ -1,8 +1,12 @@
-"""BASELINE configs[1] and configs[3] on the device, against the CPU oracle.
+"""BASELINE configs[1], configs[2] (on the reference's own scene file) and configs[3] on the device, against the CPU oracle.
 
 configs[1]  input/scene_teapot.json (the reference's own files, tests/golden/ref_inputs): teapot.obj
             import, 800x800, fixed 256 spp (16 batches of 16, all mandatory), light-PDF importance
             sampling through the quad light's attractor.
+configs[2]  input/scene.json, the scene of the README render, as the reference ships it; the dragon.obj it names is not
+            distributed, so a generated 20 000-triangle mesh stands under that name.  input/config.json's sampling (batches
+            of 20, z-test after 2) at 240x240 with at most 12 batches.  (The full-size workload with 100 000 triangles is
+            tests/test_gpu_fullsize.py.)
 configs[3]  multi-million-triangle mesh (xl_dragon.obj is not distributed: the generated knot at
             2.2 M triangles, above the size at which the library stores its nodes in line-sized blocks),
             2048x2048, 1024 spp (64 batches of 16, z-test after 4).
@@ -15,7 +19,7 @@ import pytest
 from raytracer_amd import RenderIntegrator, abi, parallel, scenes
 from oracle import oracle
 
-from helpers import assert_image_parity, noise_gate, teapot_scene
+from helpers import assert_image_parity, noise_gate, readme_scene, teapot_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -73,6 +77,27 @@ def test_c2_teapot_agrees_with_the_reference_rng_mode_within_noise(teapot):
     a = out["linear"][40::80]
     noise_gate(a, b["linear"], o["linear"], 1.10)
     assert abs(a.mean() - o["linear"].mean()) <= 0.01 * o["linear"].mean()
+
+
+# ------------------------------------------------------------------ configs[2], the reference's scene file
+def test_c3_scene_file_of_the_reference(tmp_scene_dir):
+    ri = readme_scene(tmp_scene_dir, 20000, 240, 240, 20, 12, 2)
+    res = ri.resident(0)
+    cfg = ri.config.copy()
+    assert ri.scene.contents.n_attractors == 1 and ri.scene.contents.n_quads == 1
+    pg, tg = res.primary_hits(cfg)
+    po, to = oracle.primary_hits_threads(ri.scene, cfg, 16)
+    assert np.array_equal(pg, po), f"{(pg != po).sum()} of {pg.size} primary hits name another element"
+    assert np.array_equal(tg, to)
+    n_mesh = ri.scene.contents.n_triangles - 24
+    seen = np.unique(po)
+    assert (seen < n_mesh).sum() > 500 and (po >= 0).mean() > 0.85  # the mesh is in the picture
+    out, st = res.render(cfg)
+    o, so = oracle.render(ri.scene, cfg, 16)
+    p = assert_image_parity(out, o, "input/scene.json", res, cfg)
+    assert np.array_equal(out["sample_pixels"], o["sample_pixels"]) and st.samples == so.samples
+    assert 2 * 20 < out["samples"].mean() < 12 * 20 and (out["samples"] < 12 * 20).any()  # the z-test stopped pixels early
+    ri.close()
 
 
 # ------------------------------------------------------------------ configs[3]

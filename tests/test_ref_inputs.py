@@ -10,7 +10,7 @@ import numpy as np
 from raytracer_amd import RenderIntegrator, abi, scenes
 from oracle import host_ref
 
-from helpers import REF_INPUTS, ref_config, teapot_scene
+from helpers import REF_INPUTS, readme_scene, ref_config, teapot_scene
 
 
 def test_config_json_of_the_reference():
@@ -77,3 +77,32 @@ def test_diamond_obj_of_the_reference_loads():
     nodes = [(n.is_leaf, n.element_index, n.child_l_index, n.child_r_index, tuple(n.child_l_min), tuple(n.child_l_max),
               tuple(n.child_r_min), tuple(n.child_r_max)) for n in (sc.nodes[i] for i in range(sc.n_nodes))]
     assert nodes == ref["nodes"]
+
+
+def test_readme_scene_of_the_reference_loads(tmp_scene_dir):
+    """input/scene.json (the scene of BASELINE configs[2]) through the C++ host, with a generated mesh under the name of the
+    dragon.obj the reference does not distribute: element expansion, the file's transforms and the whole SAH tree equal the
+    Python restatement's."""
+    ri = readme_scene(tmp_scene_dir, 2000, 48, 48, 4, 1, 1)
+    sc = ri.scene.contents
+    base = os.path.join(tmp_scene_dir, "readme_2000")
+    scene = json.load(open(os.path.join(REF_INPUTS, "scene.json")))
+    kinds = [list(e.keys())[0] for e in scene["elements"]]
+    assert kinds == ["JSONObj", "JSONBox"] + ["JSONTriangle"] * 12 + ["JSONQuad"]
+    assert scene["elements"][0]["JSONObj"]["filepath"] == "input/obj/dragon.obj"
+    n_mesh = sc.n_triangles - 12 - 12
+    assert 1900 <= n_mesh <= 2100 and sc.n_quads == 1 and sc.n_spheres == 0
+    assert [sc.attractors[i] for i in range(sc.n_attractors)] == [sc.n_elements - 1]
+    scene["elements"][0]["JSONObj"]["filepath"] = os.path.join(base, "input", "obj", "dragon.obj")
+    ref = host_ref.build_scene(scene, ref_config())
+    assert len(ref["triangles"]) == sc.n_triangles
+    for k in (0, 1, n_mesh // 2, n_mesh - 1, n_mesh, sc.n_triangles - 1):
+        t, r = sc.triangles[k], ref["triangles"][k]
+        assert t.v0.tuple() == r["v0"] and t.v0v1.tuple() == r["v0v1"] and t.v0v2.tuple() == r["v0v2"] and t.normal.tuple() == r["normal"], k
+    nodes = [(n.is_leaf, n.element_index, n.child_l_index, n.child_r_index, tuple(n.child_l_min), tuple(n.child_l_max),
+              tuple(n.child_r_min), tuple(n.child_r_max)) for n in (sc.nodes[i] for i in range(sc.n_nodes))]
+    assert nodes == ref["nodes"]
+    # scaled by 22, rotated about y by -3.2 and moved by (220, 0, 200): the mesh stands on the floor inside the room
+    lo = np.min([ri.element_bbox(i)[0] for i in range(n_mesh)], axis=0)
+    hi = np.max([ri.element_bbox(i)[1] for i in range(n_mesh)], axis=0)
+    assert (lo > [50, -1e-3, 50]).all() and (hi < [400, 250, 400]).all() and (hi - lo).max() > 150.0
