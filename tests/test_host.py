@@ -120,6 +120,23 @@ def test_box_expands_to_twelve_front_facing_triangles():
         assert np.dot(np.array(t.normal.tuple()), c - centre) > 0
 
 
+def test_mat4_times_point_known_answer_from_reference_tests():
+    # mat4.rs:484-511 (test_multiply_vec3): Mat4 * Vec4(v, 1), the product the element transforms apply to every vertex
+    m = [[1., 2., 3., 4.], [2., 3., 4., 5.], [3., 4., 5., 6.]]
+    assert host_ref._apply(m, (1., 2., 3.)) == (1. * 1. + 2. * 2. + 3. * 3. + 4. * 1., 2. * 1. + 3. * 2. + 4. * 3. + 5. * 1.,
+                                               3. * 1. + 4. * 2. + 5. * 3. + 6. * 1.)
+    identity = [[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.]]
+    assert host_ref._apply(identity, (1., 2., 3.)) == (1., 2., 3.)
+    # mat4.rs:28-99: the constructors the loader chains (scale, the three rotations, translation): their matrices as written there
+    assert host_ref._scale((2., 3., 4.)) == [[2., 0., 0., 0.], [0., 3., 0., 0.], [0., 0., 4., 0.]]
+    t = 0.3
+    c, sn = np.cos(t), np.sin(t)
+    assert host_ref._rot_x(t) == [[1., 0., 0., 0.], [0., c, sn, 0.], [0., -sn, c, 0.]]
+    assert host_ref._rot_y(t) == [[c, 0., -sn, 0.], [0., 1., 0., 0.], [sn, 0., c, 0.]]
+    assert host_ref._rot_z(t) == [[c, -sn, 0., 0.], [sn, c, 0., 0.], [0., 0., 1., 0.]]
+    assert host_ref._apply(host_ref._translate((5., 6., 7.)), (1., 2., 3.)) == (6., 8., 10.)
+
+
 def test_aabb_known_answers_from_reference_tests():
     # aabb.rs:337-391: centroid, largest_axis, area (half the surface area)
     b = host_ref.Aabb.from_points((0.0, 0.0, 0.0), (4.0, 2.0, 1.0))
