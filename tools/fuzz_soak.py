@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run of the random-scene parity check of tests/test_gpu_fuzz.py over many more seeds than the test suite holds:
 closest hits of random rays and primary hits against the oracle, bit for bit, and a whole render every eighth seed.
-tools/fuzz_soak.py FIRST LAST [IMAGE_EVERY=8]; the RT_HIP_* environment (e.g. RT_HIP_WIDE=1 RT_HIP_TRI_PAD=1) picks the variant.
+tools/fuzz_soak.py FIRST LAST [IMAGE_EVERY=8] [--device-build]; with --device-build the tree is the linear BVH built on the
+device and the oracle walks the downloaded copy of it (rt_hip_scene_download_tree).  The RT_HIP_* environment (e.g. RT_HIP_WIDE=1 RT_HIP_TRI_PAD=1) picks the variant.
 Pixels that differ in an image while every hit agrees are paths that a last-bit difference between the device's and libm's
 sin / cos / pow sends to the other side of an edge; the run counts them."""
 import os
@@ -16,26 +17,38 @@ from helpers import assert_image_parity, random_rays
 from oracle import oracle
 from test_gpu_fuzz import _scene
 
-first, last = int(sys.argv[1]), int(sys.argv[2])
-image_every = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+device_build = "--device-build" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+first, last = int(argv[0]), int(argv[1])
+image_every = int(argv[2]) if len(argv) > 2 else 8
 from helpers import image_parity
 images = differing_pixels = images_with_differences = 0
 t0 = time.time()
 bad_seeds = []
 for seed in range(first, last):
     ri = _scene(seed)
-    res = ri.resident(0)
+    if device_build:
+        import ctypes as C
+        from raytracer_amd.integrator import ResidentScene
+        from test_gpu_device_build import _scene_with_nodes
+        res = ResidentScene(ri.scene, 0, build_on_device=True)
+        nodes = res.download_tree()
+        twin = _scene_with_nodes(ri, nodes)
+        scene_for_oracle = C.byref(twin)
+    else:
+        res = ri.resident(0)
+        scene_for_oracle = ri.scene
     o, d = random_rays(40_000, seed=1000 + seed)
     pg, tg = res.trace_rays(o, d)
-    po, to = oracle.trace_rays(ri.scene, o, d)
+    po, to = oracle.trace_rays(scene_for_oracle, o, d)
     cfg = ri.config.copy()
     pg2, tg2 = res.primary_hits(cfg)
-    po2, to2 = oracle.primary_hits(ri.scene, cfg)
+    po2, to2 = oracle.primary_hits(scene_for_oracle, cfg)
     ok = np.array_equal(pg, po) and np.array_equal(tg, to) and np.array_equal(pg2, po2) and np.array_equal(tg2, to2)
     if ok and seed % image_every == 0:
         cfg.sample_batch_size, cfg.max_sample_batches, cfg.min_sample_batches = 8, 4, 0
         out_g, st_g = res.render(cfg)
-        out_o, st_o = oracle.render(ri.scene, cfg, 8)
+        out_o, st_o = oracle.render(scene_for_oracle, cfg, 8)
         n_differ = image_parity(out_g, out_o)["n_differ"]
         images += 1
         differing_pixels += n_differ
@@ -48,6 +61,8 @@ for seed in range(first, last):
     if not ok:
         bad_seeds.append(seed)
         print("MISMATCH seed", seed, int(((pg != po) | (tg != to)).sum()), int(((pg2 != po2) | (tg2 != to2)).sum()), flush=True)
+    if device_build:
+        res.close()
     ri.close()
     if (seed - first) % 25 == 24:
         print(f"  {seed - first + 1} seeds, {time.time() - t0:.0f} s, mismatching so far: {bad_seeds}", flush=True)
