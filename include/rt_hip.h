@@ -255,6 +255,9 @@ typedef struct RtStats {
   uint64_t wave_cycles_refill;
   uint64_t wave_cycles_node;
   uint64_t wave_cycles_leaf;
+  /* device, with RT_FLAG_COUNT_VISITS: on trees too high for every lane's traversal stack to stay in on-chip memory, how
+   * often a block of stack entries was moved out to device memory or fetched back (0 on lower trees) */
+  uint64_t stack_block_moves;
 } RtStats;
 
 typedef struct RtSceneHandle RtSceneHandle;

@@ -155,6 +155,7 @@ class RtStats(C.Structure):
         ("wave_cycles_refill", C.c_uint64),
         ("wave_cycles_node", C.c_uint64),
         ("wave_cycles_leaf", C.c_uint64),
+        ("stack_block_moves", C.c_uint64),
     ]
 
 

@@ -34,17 +34,20 @@ constexpr uint32_t kRefIndexMask = 0x0fffffffu;
 constexpr uint32_t kRefNone = 0xffffffffu;
 constexpr int kRefKindShift = 29;
 constexpr int kMaxStackDepth = 64;
-#ifndef RT_LDS_LEVELS
-#define RT_LDS_LEVELS 24
-#endif
 #ifndef RT_SPILL_ABOVE
-#define RT_SPILL_ABOVE 27
+#define RT_SPILL_ABOVE 22
 #endif
-constexpr int kLdsStackLevels = RT_LDS_LEVELS;  // stack entries per lane held in LDS by the order-free walk once it spills
-constexpr int kSpillAboveDepth = RT_SPILL_ABOVE; // trees up to this height keep the whole stack in LDS: (27 + 4 leaf-queue levels) x 256 B
-                                     // per wave still lets 20 waves (the register limit) share a CU's 160 KB; measured on a
-                                     // 2 M-triangle scene: height 26 all in LDS 1243 ms, spilling above 24 levels 1315 ms;
-                                     // height 38 all in LDS 1649 ms, 28 levels in LDS 1478 ms, 24 levels 1396 ms
+#ifndef RT_OVF_LEVELS
+#define RT_OVF_LEVELS 16
+#endif
+constexpr int kLdsStackLevels = 24;               // default of the LDSL argument of the stack functions (the wide walk passes its own)
+constexpr int kSpillAboveDepth = RT_SPILL_ABOVE;  // trees up to this height keep the whole stack of the binary order-free walks in LDS: six
+                                     // waves per SIMD (24 stacks per CU) have room for 22 levels + the leaf queue each.  Higher trees take the
+                                     // block-overflow stack (StackRef below), whose LDS footprint does not depend on the tree.  Measured on a 2 M-triangle
+                                     // scene at 2048 x 2048: the reference-order SAH tree (height 26) all in LDS at five waves 1124 ms, overflow stack at
+                                     // six waves 1070 ms; the device-built linear BVH (height 38) 1255 ms with the levels above 24 in global memory
+                                     // slot by slot at five waves, 1116 ms with the overflow stack.  On a tree of height 21 that has the choice the
+                                     // overflow stack is 2 % slower than the whole stack in LDS (650 against 635 ms).
 
 // 64-byte internal node: both child boxes (f32, rounded outward) + child refs.
 struct __attribute__((aligned(64))) DevNode {
@@ -141,9 +144,8 @@ struct DevScene {
   int32_t n_materials;
   uint32_t root;        // ref of nodes[0] of the reference array
   int32_t stack_depth;  // stack entries a lane can need (the height of the tree)
-  // The order-free walk keeps the first kLdsStackLevels entries of a lane's stack in LDS; a deeper tree (a
-  // linear BVH built on the device is about twice as high as a SAH tree) spills the rest to this buffer,
-  // laid out [level][wave][lane], so that the LDS footprint of a wave does not cost occupancy.
+  // Global-memory part of the traversal stacks, [level][wave][lane]: the blocks of entries the binary order-free walks move out
+  // of LDS on trees too high for it, and the wide walk's levels beyond kWideLdsLevels; null when no walk of the scene needs it.
   uint32_t *stack_spill;
   int32_t quirk;        // 1 when the walk must follow the reference's visit rule step by step: some child box
                         // does not contain the primitives below it, or the nodes do not form a tree
@@ -570,6 +572,7 @@ struct Traversal {
   u16x2 m01, m23;    // QUIRK: per deferred leaf, the lowest stack height since it was queued
   float tcull;       // !QUIRK: best.t rounded up to f32 (+inf before the first hit)
   Hit best;
+  uint32_t moves;    // blocks of stack entries moved between LDS and global memory (counted over the lane's whole life)
 };
 
 // A direction component of exactly -0.0: Ray::new takes its sign as positive (`-0.0 < 0.0` is false, ray.rs:44-46) and its
@@ -592,26 +595,72 @@ RT_DEV void trav_begin(uint32_t root, Traversal &tv) {
   tv.best.ref = kRefNone;
 }
 
-// A lane's stack: LDS for the first levels, global memory beyond (SPILL instantiations only).
+// A lane's stack.  Three ways to hold it (template argument SPILL of the functions below):
+//   0  every level in LDS;
+//   1  the first LDSL levels in LDS, level LDSL and above in global memory, one slot per level;
+//   2  the newest entries in kOvfLevels levels of LDS.  A push that finds them full moves the oldest kOvfBlock entries out to
+//      global memory as a block and slides the rest down; a pop that finds LDS empty fetches the newest block back.  The number
+//      of blocks outside is kept in the LDS row after the stack's (zero whenever a walk starts: a walk ends with its stack
+//      drained).  Both moves are rare -- a walk that enters the nearer child first seldom holds more than a dozen entries however
+//      high the tree -- and sit in cold branches, so the step costs one compare more than mode 0 and the LDS footprint no longer
+//      depends on the tree.
+constexpr int kOvfLevels = RT_OVF_LEVELS, kOvfBlock = 8;
 struct StackRef {
   uint32_t *lds;     // this lane's slot of level 0; levels are 64 entries apart
-  uint32_t *spill;   // this lane's slot of the first spilled level; levels are `spill_stride` entries apart
-  uint32_t spill_stride;
+  uint32_t *spill;   // mode 1: this lane's slot of the first spilled level; mode 2: the wave's first slot of the buffer
+  uint32_t spill_stride;  // entries between two levels of the buffer
 };
-template <bool SPILL, int LDSL = kLdsStackLevels>
+template <int SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void stack_store(const StackRef &s, int level, uint32_t v) {
-  if (!SPILL || level < LDSL) s.lds[level * 64] = v;
+  if (SPILL != 1 || level < LDSL) s.lds[level * 64] = v;
   else s.spill[(size_t)(level - LDSL) * s.spill_stride] = v;
 }
-template <bool SPILL, int LDSL = kLdsStackLevels>
+template <int SPILL, int LDSL = kLdsStackLevels>
 RT_DEV uint32_t stack_load(const StackRef &s, int level) {
-  if (!SPILL || level < LDSL) return s.lds[level * 64];
+  if (SPILL != 1 || level < LDSL) return s.lds[level * 64];
   return s.spill[(size_t)(level - LDSL) * s.spill_stride];
 }
+// mode 2: this lane's slot of level `level` of the global buffer.  The lane number passes through an empty asm statement
+// so that the address is formed here, in the cold branch, and does not occupy registers through the whole walk.
+RT_DEV uint32_t *stack_block_slot(const StackRef &s, uint32_t level) {
+  uint32_t l = threadIdx.x;
+  asm volatile("" : "+v"(l));
+  return s.spill + (size_t)level * s.spill_stride + l;
+}
+RT_DEV void stack_block_out(Traversal &tv, const StackRef &s) {
+  const uint32_t nb = s.lds[kOvfLevels * 64];
+#pragma unroll
+  for (int k = 0; k < kOvfBlock; k++) {
+    *stack_block_slot(s, nb * kOvfBlock + k) = s.lds[k * 64];
+    s.lds[k * 64] = s.lds[(k + kOvfBlock) * 64];
+  }
+  s.lds[kOvfLevels * 64] = nb + 1u;
+  tv.sp = kOvfLevels - kOvfBlock;
+  tv.moves++;
+}
+template <int SPILL, int LDSL = kLdsStackLevels>
+RT_DEV void stack_push(Traversal &tv, const StackRef &s, uint32_t v) {
+  if (SPILL == 2 && __builtin_expect(tv.sp == kOvfLevels, 0)) stack_block_out(tv, s);
+  stack_store<SPILL, LDSL>(s, tv.sp, v);
+  tv.sp++;
+}
 // the order-free walk's pop: entries are children whose box the ray hits
-template <bool SPILL, int LDSL = kLdsStackLevels>
+template <int SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void trav_pop_fast(Traversal &tv, const StackRef &s) {
   if (tv.sp == 0) {
+    if (SPILL == 2) {
+      uint32_t nb = s.lds[kOvfLevels * 64];
+      if (nb != 0u) {  // the newest block comes back
+        nb--;
+#pragma unroll
+        for (int k = 0; k < kOvfBlock; k++) s.lds[k * 64] = *stack_block_slot(s, nb * kOvfBlock + k);
+        s.lds[kOvfLevels * 64] = nb;
+        tv.moves++;
+        tv.sp = kOvfBlock - 1;
+        tv.cur = s.lds[tv.sp * 64];
+        return;
+      }
+    }
     tv.cur = kDone;
   } else {
     tv.sp--;
@@ -663,7 +712,7 @@ RT_DEV void trav_pop(Traversal &tv, const uint32_t *stack, int stride) {
 // contents, so which leaves are tested, and in which order, cannot change the result
 // (trav_test_leaf breaks ties by the reference's leaf order).  Enter the nearer child first and
 // drop children that begin beyond the closest hit so far.
-template <bool SPILL>
+template <int SPILL>
 RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, const StackRef &stack) {
   const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
   float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
@@ -673,8 +722,7 @@ RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, con
   bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
   if (hl && hr) {
     bool swap = tr < tl;
-    stack_store<SPILL>(stack, tv.sp, swap ? left : right);
-    tv.sp++;
+    stack_push<SPILL>(tv, stack, swap ? left : right);
     tv.cur = swap ? right : left;
   } else if (hl || hr) {
     tv.cur = hl ? left : right;
@@ -738,7 +786,7 @@ RT_DEV void trav_node_ref(const DevScene &sc, const RayF &f, Traversal &tv, uint
 }
 
 // The node step on the 32-byte grid records (order-free walk only).
-template <bool SPILL>
+template <int SPILL>
 RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const StackRef &stack) {
   const uint4 *p = reinterpret_cast<const uint4 *>(&sc.nodes_q[tv.cur & kRefIndexMask]);
   uint4 w0 = p[0], w1 = p[1];
@@ -758,8 +806,7 @@ RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const 
 #endif
   if (hl && hr) {
     bool swap = tr < tl;
-    stack_store<SPILL>(stack, tv.sp, swap ? left : right);
-    tv.sp++;
+    stack_push<SPILL>(tv, stack, swap ? left : right);
     tv.cur = swap ? right : left;
   } else if (hl || hr) {
     tv.cur = hl ? left : right;
@@ -771,7 +818,7 @@ RT_DEV void trav_node_q(const DevScene &sc, const RayQ &r, Traversal &tv, const 
 // The node step on the 64-byte wide records (order-free walk only): four box tests behind one memory round trip.
 // A child that is a leaf goes straight into the leaf queue while there is room; of the others the nearest is
 // entered and the rest are pushed.  Which children are entered in which order cannot change the result.
-template <bool SPILL>
+template <int SPILL>
 RT_DEV void trav_node_w(const DevScene &sc, const RayQ &r, Traversal &tv, const StackRef &stack, uint32_t *leafq, int leafq_cap) {
   const uint4 *p = reinterpret_cast<const uint4 *>(&sc.nodes_w[tv.cur & kRefIndexMask]);
   const uint4 wx = p[0], wy = p[1], wz = p[2], rf = p[3];
@@ -814,7 +861,7 @@ RT_DEV void trav_node_w(const DevScene &sc, const RayQ &r, Traversal &tv, const 
 }
 
 // Queue the leaf in `cur` for the next leaf phase and move on (order-free walk).
-template <bool SPILL, int LDSL = kLdsStackLevels>
+template <int SPILL, int LDSL = kLdsStackLevels>
 RT_DEV void trav_defer_leaf_fast(Traversal &tv, const StackRef &stack, uint32_t *leafq) {
   leafq[tv.qn * 64] = tv.cur;
   tv.qn++;

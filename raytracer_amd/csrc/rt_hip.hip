@@ -333,11 +333,15 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   const int stride = 64;
   uint32_t *stack = g_lds + lane;
   static_assert(!WIDE || (GRID && !QUIRK), "wide nodes exist on the grid, for the order-free walk");
-  constexpr int kLdsl = WIDE ? kWideLdsLevels : kLdsStackLevels;
+  // how the stack is held (rt_device.h, StackRef): all in LDS; the wide walk's levels beyond kWideLdsLevels in global memory; the
+  // binary walks' newest kOvfLevels entries in LDS with blocks of older ones moved out
+  constexpr int SM = !SPILL ? 0 : (WIDE ? 1 : 2);
+  constexpr int kLdsl = WIDE ? kWideLdsLevels : kOvfLevels + 1;
   const uint32_t root = WIDE ? sc.root_w : sc.root;
   const int lds_levels = SPILL ? kLdsl : (WIDE ? sc.stack_depth_w : sc.stack_depth);
   uint32_t *leafq = g_lds + (size_t)lds_levels * 64 + lane;
-  const StackRef sref = {stack, SPILL ? sc.stack_spill + (size_t)blockIdx.x * 64 + lane : nullptr, gridDim.x * 64u};
+  const StackRef sref = {stack, SM == 0 ? nullptr : sc.stack_spill + (size_t)blockIdx.x * 64 + (SM == 1 ? lane : 0u), gridDim.x * 64u};
+  if (SM == 2) stack[kOvfLevels * 64] = 0u;  // blocks of this lane's stack outside LDS
   const uint32_t home = blockIdx.x % kRegions;
   const uint32_t waves_per_region = gridDim.x / kRegions;
   uint32_t region_try = 0;         // regions tried so far (wave-uniform)
@@ -352,6 +356,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   Traversal tv;
   trav_begin(root, tv);
   tv.cur = kDone;
+  tv.moves = 0;
   uint32_t nn = 0, nl = 0, wn = 0, wl = 0;  // lane and wave step counts (COUNT only)
   uint32_t d_idle = 0, d_done = 0, d_block = 0;
   unsigned long long cyc_refill = 0, cyc_node = 0, cyc_leaf = 0, cyc_mark = 0;  // shader cycles of the wave per phase (COUNT only)
@@ -433,24 +438,24 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         if (COUNT) nn++;
         if (QUIRK && sc.nodes_d) trav_node_ref_exact(sc, ro, rd, rinv, tv, stack, stride);
         else if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
-        else if (WIDE) trav_node_w<SPILL>(sc, fq, tv, sref, leafq, tune.leafq);
-        else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
-        else trav_node_fast<SPILL>(sc, f, tv, sref);
+        else if (WIDE) trav_node_w<SM>(sc, fq, tv, sref, leafq, tune.leafq);
+        else if (GRID) trav_node_q<SM>(sc, fq, tv, sref);
+        else trav_node_fast<SM>(sc, f, tv, sref);
       }
       if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) {
         if (QUIRK) trav_defer_leaf<true>(tv, stack, leafq, stride);
-        else trav_defer_leaf_fast<SPILL, kLdsl>(tv, sref, leafq);
+        else trav_defer_leaf_fast<SM, kLdsl>(tv, sref, leafq);
       }
 #pragma unroll
       for (int extra = 0; extra < (QUIRK ? 0 : WIDE ? RT_EXTRA_STEPS_WIDE : RT_EXTRA_STEPS); extra++) {  // more steps before the wave votes again
         if (COUNT) wn++;
         if (!(tv.cur & kRefLeaf)) {
           if (COUNT) nn++;
-          if (WIDE) trav_node_w<SPILL>(sc, fq, tv, sref, leafq, tune.leafq);
-          else if (GRID) trav_node_q<SPILL>(sc, fq, tv, sref);
-          else trav_node_fast<SPILL>(sc, f, tv, sref);
+          if (WIDE) trav_node_w<SM>(sc, fq, tv, sref, leafq, tune.leafq);
+          else if (GRID) trav_node_q<SM>(sc, fq, tv, sref);
+          else trav_node_fast<SM>(sc, f, tv, sref);
         }
-        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SPILL, kLdsl>(tv, sref, leafq);
+        if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SM, kLdsl>(tv, sref, leafq);
       }
     } while (__popcll(__ballot(!(tv.cur & kRefLeaf))) >= tune.node_min);
     RT_PHASE_END(cyc_node)
@@ -516,6 +521,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
     atomicAdd(&visit_counters[8], (unsigned long long)d_idle);
     atomicAdd(&visit_counters[9], (unsigned long long)d_done);
     atomicAdd(&visit_counters[10], (unsigned long long)d_block);
+    if (SM == 2) atomicAdd(&visit_counters[11], (unsigned long long)tv.moves);
     if (lane == 0) {
       atomicAdd(&visit_counters[3], (unsigned long long)wn);
       atomicAdd(&visit_counters[4], (unsigned long long)wl);
@@ -536,15 +542,21 @@ static ExtendTuning extend_tuning() {
   return t;
 }
 
-// The walk that follows the reference's rule keeps its whole stack in LDS; the order-free walk at most kLdsStackLevels levels.
+// The walk that follows the reference's rule keeps its whole stack in LDS.
 static bool extend_wide(const DevScene &sc, bool quirk) { return !quirk && sc.nodes_w != nullptr; }
+// The binary order-free walks move blocks of stack entries out of LDS (rt_device.h, StackRef) exactly when upload gave the scene a
+// buffer for them: trees higher than `spill_above_depth()`.
+static int spill_above_depth() {
+  const char *e = getenv("RT_HIP_SPILL_ABOVE");
+  return e ? std::max(kOvfLevels, atoi(e)) : kSpillAboveDepth;
+}
 static bool extend_spills(const DevScene &sc, bool quirk) {
   if (extend_wide(sc, quirk)) return sc.stack_depth_w > kWideLdsLevels;
-  return !quirk && sc.stack_depth > kSpillAboveDepth && sc.stack_spill != nullptr;
+  return !quirk && sc.stack_spill != nullptr;
 }
 static size_t extend_lds_bytes(const DevScene &sc, bool quirk) {
   const bool wide = extend_wide(sc, quirk);
-  const int levels = extend_spills(sc, quirk) ? (wide ? kWideLdsLevels : kLdsStackLevels) : (wide ? sc.stack_depth_w : sc.stack_depth);
+  const int levels = extend_spills(sc, quirk) ? (wide ? kWideLdsLevels : kOvfLevels + 1) : (wide ? sc.stack_depth_w : sc.stack_depth);
   return (size_t)(levels + kMaxLeafQueue) * 64 * sizeof(uint32_t);
 }
 constexpr int kMaxExtendWaves = 256 * 32;  // 256 CUs x 32 wave slots
@@ -552,8 +564,8 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 // Waves per SIMD the kernel's registers are budgeted for (template argument WAVES): the walk is bound by VALU issue with
 // part of its memory latency exposed, and a sixth wave (80 instead of 88 registers, a few loop-invariant values in
 // scratch) hides more of it than the tighter budget costs (C3: 688 -> 654 ms).  Seven waves (72 registers) spill inside the loops
-// (1076 ms).  Six waves need 24 stacks per CU in LDS, so only trees up to height 22 get that variant; the counting and reference-rule
-// variants take what they need.
+// (1076 ms).  Six waves need 24 stacks per CU in LDS: trees up to height 22 keep the whole stack there, higher ones take the
+// block-overflow stack (17 rows of LDS whatever the height); the counting and reference-rule variants take what they need.
 
 // `counts` = entries per region, `work` = claim counters per region (zeroed by the caller); both
 // kCounterStride words apart.
@@ -589,8 +601,11 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
 #undef RT_LAUNCH_WIDE
   } else if (sc.nodes_q) {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true, 4); else RT_LAUNCH_EXTEND(false, true, true, false, 4); }
-    else if (spill) RT_LAUNCH_EXTEND(false, false, true, true, 5);
-    else if (lds * 24 <= kLdsPerCu) RT_LAUNCH_EXTEND(false, false, true, false, 6);  // the production kernel on trees up to height 22
+    else if (spill) {
+      static const int ovf_waves = getenv("RT_HIP_OVF_WAVES") ? atoi(getenv("RT_HIP_OVF_WAVES")) : 6;
+      if (ovf_waves >= 6) RT_LAUNCH_EXTEND(false, false, true, true, 6);
+      else RT_LAUNCH_EXTEND(false, false, true, true, 5);
+    } else if (lds * 24 <= kLdsPerCu) RT_LAUNCH_EXTEND(false, false, true, false, 6);  // the production kernel on trees up to height 22
     else RT_LAUNCH_EXTEND(false, false, true, false, 5);
   } else {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, false, true, 4); else RT_LAUNCH_EXTEND(false, true, false, false, 4); }
@@ -1593,7 +1608,9 @@ static int validate_primitives(const RtScene *s) {
 // Global-memory part of the traversal stacks of a tree higher than the LDS part holds: [level][wave][lane].
 static int alloc_stack_spill(RtSceneHandle *h) {
   h->dev.stack_spill = nullptr;
-  int levels = h->dev.stack_depth > kSpillAboveDepth ? h->dev.stack_depth - kLdsStackLevels : 0;
+  // binary walks: blocks of kOvfBlock entries leave LDS when a push finds kOvfLevels there, i.e. with 16 + 8 b entries on the stack
+  // and b blocks outside, and the stack never holds more entries than the tree is high
+  int levels = h->dev.stack_depth > spill_above_depth() ? ((h->dev.stack_depth - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock : 0;
   if (h->dev.nodes_w) levels = std::max(levels, h->dev.stack_depth_w - kWideLdsLevels);
   if (levels <= 0) return RT_OK;
   return dev_alloc(h, &h->dev.stack_spill, (size_t)levels * kMaxExtendWaves * 64);
@@ -2266,7 +2283,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
-  constexpr int kTotals = RT_MAX_DEPTH_STATS + 13;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire
+  constexpr int kTotals = RT_MAX_DEPTH_STATS + 13;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire, [25..27] lane states, [28] stack block moves
   unsigned long long *totals;
   PixelOutputs po{};
   // k_accumulate appends the surviving pixels wave by wave in whatever order the waves finish;
@@ -2475,6 +2492,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     stats->wave_cycles_refill = host_totals[RT_MAX_DEPTH_STATS + 6];
     stats->wave_cycles_node = host_totals[RT_MAX_DEPTH_STATS + 7];
     stats->wave_cycles_leaf = host_totals[RT_MAX_DEPTH_STATS + 8];
+    stats->stack_block_moves = host_totals[RT_MAX_DEPTH_STATS + 12];
     if (getenv("RT_HIP_VERBOSE") && host_totals[RT_MAX_DEPTH_STATS + 4]) {
       // sampled at the first of the 1 + RT_EXTRA_STEPS node steps between two votes (the reference-rule walk votes after every step)
       const double sampled_slots = 64.0 * host_totals[RT_MAX_DEPTH_STATS + 4] / (walk == 1 ? 1.0 : 1.0 + RT_EXTRA_STEPS);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--triangles", type=int, default=2_000_000)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-batches", type=int, default=64)
+    ap.add_argument("--no-count", action="store_true", help="time the production kernels (the visit-counting ones run at four waves per SIMD)")
     args = ap.parse_args()
     from raytracer_amd import RenderIntegrator, abi, scenes
     from raytracer_amd.integrator import ResidentScene
@@ -33,14 +34,14 @@ def main():
     host = ResidentScene(ri.scene, 0)
     t2 = time.perf_counter()
     cfg = ri.config.copy()
-    cfg.flags = abi.RT_FLAG_TIME_KERNELS | abi.RT_FLAG_COUNT_VISITS
+    cfg.flags = abi.RT_FLAG_TIME_KERNELS | (0 if args.no_count else abi.RT_FLAG_COUNT_VISITS)
     host.render(cfg)  # first render pays for the working memory
     t3 = time.perf_counter()
     _, st = host.render(cfg)
     t4 = time.perf_counter()
     out["host_tree"] = {"load_expand_build_s": t1 - t0, "upload_s": t2 - t1, "first_render_s": t3 - t2, "render_s": t4 - t3,
                         "mrays_per_s": st.rays / (t4 - t3) / 1e6, "extend_ms": st.trace_kernel_ms, "shade_ms": st.shade_kernel_ms,
-                        "node_visits_per_ray": st.node_visits / st.rays_traced, "leaf_tests_per_ray": st.leaf_tests / st.rays_traced,
+                        "node_visits_per_ray": st.node_visits / max(st.rays_traced, 1), "leaf_tests_per_ray": st.leaf_tests / max(st.rays_traced, 1),
                         "bvh_depth": ri.bvh_depth()}
     host.close()
     # device path: the same primitives (the host's tree is ignored), tree built on the GPU
@@ -53,7 +54,7 @@ def main():
     t8 = time.perf_counter()
     out["device_tree"] = {"copy_and_build_s": t6 - t5, "first_render_s": t7 - t6, "render_s": t8 - t7, "mrays_per_s": sd.rays / (t8 - t7) / 1e6,
                           "extend_ms": sd.trace_kernel_ms, "shade_ms": sd.shade_kernel_ms,
-                          "node_visits_per_ray": sd.node_visits / sd.rays_traced, "leaf_tests_per_ray": sd.leaf_tests / sd.rays_traced}
+                          "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1)}
     out["note"] = "load_expand_build_s includes OBJ parsing and element expansion, which the device path needs too (it starts from the expanded primitives)"
     print(json.dumps(out))
 
