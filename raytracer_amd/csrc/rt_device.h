@@ -853,10 +853,10 @@ RT_DEV void trav_node_w(const DevScene &sc, const RayQ &r, Traversal &tv, const 
     return;
   }
   const uint32_t ni = kmin & 3u;
-  if (h0 && ni != 0u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.x); tv.sp++; }
-  if (h1 && ni != 1u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.y); tv.sp++; }
-  if (h2 && ni != 2u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.z); tv.sp++; }
-  if (h3 && ni != 3u) { stack_store<SPILL, kWideLdsLevels>(stack, tv.sp, rf.w); tv.sp++; }
+  if (h0 && ni != 0u) { stack_push<SPILL, kWideLdsLevels>(tv, stack, rf.x); }
+  if (h1 && ni != 1u) { stack_push<SPILL, kWideLdsLevels>(tv, stack, rf.y); }
+  if (h2 && ni != 2u) { stack_push<SPILL, kWideLdsLevels>(tv, stack, rf.z); }
+  if (h3 && ni != 3u) { stack_push<SPILL, kWideLdsLevels>(tv, stack, rf.w); }
   tv.cur = ni == 0u ? rf.x : ni == 1u ? rf.y : ni == 2u ? rf.z : rf.w;
 }
 

@@ -309,6 +309,9 @@ constexpr uint32_t kClaim = 512;
 #ifndef RT_EXTRA_STEPS_WIDE
 #define RT_EXTRA_STEPS_WIDE 1  // the same for the walk on wide nodes
 #endif
+#ifndef RT_WIDE_STACK_MODE
+#define RT_WIDE_STACK_MODE 1
+#endif
 #ifndef RT_SPLIT_LEAF
 #define RT_SPLIT_LEAF 1
 #endif
@@ -335,8 +338,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   static_assert(!WIDE || (GRID && !QUIRK), "wide nodes exist on the grid, for the order-free walk");
   // how the stack is held (rt_device.h, StackRef): all in LDS; the wide walk's levels beyond kWideLdsLevels in global memory; the
   // binary walks' newest kOvfLevels entries in LDS with blocks of older ones moved out
-  constexpr int SM = !SPILL ? 0 : (WIDE ? 1 : 2);
-  constexpr int kLdsl = WIDE ? kWideLdsLevels : kOvfLevels + 1;
+  constexpr int SM = !SPILL ? 0 : (WIDE ? RT_WIDE_STACK_MODE : 2);
+  constexpr int kLdsl = SM == 1 ? kWideLdsLevels : kOvfLevels + 1;
   const uint32_t root = WIDE ? sc.root_w : sc.root;
   const int lds_levels = SPILL ? kLdsl : (WIDE ? sc.stack_depth_w : sc.stack_depth);
   uint32_t *leafq = g_lds + (size_t)lds_levels * 64 + lane;
@@ -556,7 +559,7 @@ static bool extend_spills(const DevScene &sc, bool quirk) {
 }
 static size_t extend_lds_bytes(const DevScene &sc, bool quirk) {
   const bool wide = extend_wide(sc, quirk);
-  const int levels = extend_spills(sc, quirk) ? (wide ? kWideLdsLevels : kOvfLevels + 1) : (wide ? sc.stack_depth_w : sc.stack_depth);
+  const int levels = extend_spills(sc, quirk) ? (wide && RT_WIDE_STACK_MODE == 1 ? kWideLdsLevels : kOvfLevels + 1) : (wide ? sc.stack_depth_w : sc.stack_depth);
   return (size_t)(levels + kMaxLeafQueue) * 64 * sizeof(uint32_t);
 }
 constexpr int kMaxExtendWaves = 256 * 32;  // 256 CUs x 32 wave slots
@@ -1611,7 +1614,8 @@ static int alloc_stack_spill(RtSceneHandle *h) {
   // binary walks: blocks of kOvfBlock entries leave LDS when a push finds kOvfLevels there, i.e. with 16 + 8 b entries on the stack
   // and b blocks outside, and the stack never holds more entries than the tree is high
   int levels = h->dev.stack_depth > spill_above_depth() ? ((h->dev.stack_depth - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock : 0;
-  if (h->dev.nodes_w) levels = std::max(levels, h->dev.stack_depth_w - kWideLdsLevels);
+  if (h->dev.nodes_w && h->dev.stack_depth_w > kWideLdsLevels)
+    levels = std::max(levels, RT_WIDE_STACK_MODE == 1 ? h->dev.stack_depth_w - kWideLdsLevels : ((h->dev.stack_depth_w - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock);
   if (levels <= 0) return RT_OK;
   return dev_alloc(h, &h->dev.stack_spill, (size_t)levels * kMaxExtendWaves * 64);
 }

@@ -42,6 +42,7 @@ def main():
     out["host_tree"] = {"load_expand_build_s": t1 - t0, "upload_s": t2 - t1, "first_render_s": t3 - t2, "render_s": t4 - t3,
                         "mrays_per_s": st.rays / (t4 - t3) / 1e6, "extend_ms": st.trace_kernel_ms, "shade_ms": st.shade_kernel_ms,
                         "node_visits_per_ray": st.node_visits / max(st.rays_traced, 1), "leaf_tests_per_ray": st.leaf_tests / max(st.rays_traced, 1),
+                        "stack_block_moves_per_ray": st.stack_block_moves / max(st.rays_traced, 1),
                         "bvh_depth": ri.bvh_depth()}
     host.close()
     # device path: the same primitives (the host's tree is ignored), tree built on the GPU
@@ -54,7 +55,8 @@ def main():
     t8 = time.perf_counter()
     out["device_tree"] = {"copy_and_build_s": t6 - t5, "first_render_s": t7 - t6, "render_s": t8 - t7, "mrays_per_s": sd.rays / (t8 - t7) / 1e6,
                           "extend_ms": sd.trace_kernel_ms, "shade_ms": sd.shade_kernel_ms,
-                          "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1)}
+                          "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1),
+                          "stack_block_moves_per_ray": sd.stack_block_moves / max(sd.rays_traced, 1), "bvh_depth": dev.bvh_depth() if hasattr(dev, "bvh_depth") else None}
     out["note"] = "load_expand_build_s includes OBJ parsing and element expansion, which the device path needs too (it starts from the expanded primitives)"
     print(json.dumps(out))
 
