@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(256) k_refit_pass(int32_t n_internal, const ui
 // `slot_in_kind[e]` = position of element e among the quad (sphere) elements, in element order.
 __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *ids, const uint32_t *tri_pos, const uint32_t *slot_in_kind,
                                                      const RtElementRef *elements, const RtTriangle *tris, const RtQuad *quads, const RtSphere *spheres,
-                                                     DevTriangle *out_tris, DevTriShade *out_shade, DevQuad *out_quads, DevSphere *out_spheres,
-                                                     uint32_t *leaf_ref) {
+                                                     DevTriangle *out_tris, uint32_t tri_stride, DevTriShade *out_shade, DevQuad *out_quads,
+                                                     DevSphere *out_spheres, uint32_t *leaf_ref) {
   for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     uint32_t e = ids[j];
     RtElementRef er = elements[e];
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *i
       d.e2[0] = t.v0v2.x; d.e2[1] = t.v0v2.y; d.e2[2] = t.v0v2.z;
       d.element = e;
       d.rank = (uint32_t)j;
-      out_tris[slot] = d;
+      *reinterpret_cast<DevTriangle *>(reinterpret_cast<char *>(out_tris) + (size_t)slot * tri_stride) = d;  // records tri_stride bytes apart
       DevTriShade sh;
       sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
       sh.material = t.material;
@@ -426,13 +426,22 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   DevTriShade *o_shade;
   DevQuad *o_quads;
   DevSphere *o_spheres;
-  if ((rc = dev_alloc(h, &o_tris, n_tri_el)) != RT_OK || (rc = dev_alloc(h, &o_shade, n_tri_el)) != RT_OK ||
-      (rc = dev_alloc(h, &o_quads, n_quad_el)) != RT_OK || (rc = dev_alloc(h, &o_spheres, n_sph_el)) != RT_OK)
+  // triangle records beyond the caches one per 128-byte line, as in an upload
+  const char *pad_env = getenv("RT_HIP_TRI_PAD");
+  const bool padded = pad_env ? atoi(pad_env) != 0 : n_tri_el * sizeof(DevTriangle) > ((size_t)256 << 20);
+  const uint32_t tri_stride = padded ? 128u : (uint32_t)sizeof(DevTriangle);
+  {
+    char *bytes = nullptr;
+    if ((rc = dev_alloc(h, &bytes, n_tri_el * tri_stride)) != RT_OK) return rc;
+    o_tris = reinterpret_cast<DevTriangle *>(bytes);
+  }
+  if ((rc = dev_alloc(h, &o_shade, n_tri_el)) != RT_OK || (rc = dev_alloc(h, &o_quads, n_quad_el)) != RT_OK ||
+      (rc = dev_alloc(h, &o_spheres, n_sph_el)) != RT_OK)
     return rc;
-  hipLaunchKernelGGL(k_emit_prims, dim3(grid), dim3(block), 0, st, n, ids, d_tri_pos, d_slot, d_elements, d_tris, d_quads, d_spheres, o_tris, o_shade,
-                     o_quads, o_spheres, d_leaf_ref);
+  hipLaunchKernelGGL(k_emit_prims, dim3(grid), dim3(block), 0, st, n, ids, d_tri_pos, d_slot, d_elements, d_tris, d_quads, d_spheres, o_tris, tri_stride,
+                     o_shade, o_quads, o_spheres, d_leaf_ref);
   h->dev.triangles = o_tris;
-  h->dev.tri_stride = (uint32_t)sizeof(DevTriangle);
+  h->dev.tri_stride = tri_stride;
   h->dev.tri_shade = o_shade;
   h->dev.quads = o_quads;
   h->dev.spheres = o_spheres;
@@ -497,9 +506,28 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   h->dev.nodes_q = use_grid ? o_nodes_q : nullptr;
   h->dev.nodes_d = nullptr;
   h->dev.nodes_w = nullptr;
-  h->dev.root_w = 0;
+  h->dev.root_w = root_ref;
   h->dev.stack_depth_w = 1;
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = gridc.mn[a], h->dev.grid_step[a] = gridc.step[a];
+  // Trees beyond the caches also get the wide records of an upload, made the same way: the binary grid records come back to
+  // the host, collapse_to_wide opens them four at a time, the result goes up (10 M triangles: 0.3 GB down, 0.3 GB up and one
+  // pass of one host thread over the nodes: most of the preparation then, and still a fraction of a host build's).
+  if (use_grid && wide_nodes_wanted((size_t)n_internal)) {
+    auto t_w0 = std::chrono::steady_clock::now();
+    std::vector<DevNodeQ> host_q((size_t)n_internal);
+    HIP_TRY(hipMemcpy(host_q.data(), o_nodes_q, host_q.size() * sizeof(DevNodeQ), hipMemcpyDeviceToHost));
+    std::vector<DevNodeW> nodes_w;
+    int32_t stack_depth_w = 1;
+    collapse_to_wide(host_q, root_ref, gridc.step, nodes_w, stack_depth_w);
+    if (!nodes_w.empty()) {
+      if ((rc = dev_upload(h, &h->dev.nodes_w, nodes_w)) != RT_OK) return rc;
+      h->dev.root_w = 0;
+      h->dev.stack_depth_w = stack_depth_w;
+    }
+    if (verbose)
+      fprintf(stderr, "rt_hip build: %zu wide nodes for %d binary ones, stack need %d, %.1f ms\n", nodes_w.size(), n_internal, stack_depth_w,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_w0).count());
+  }
 
   // materials and attractors as in an upload
   std::vector<DevMaterial> mats((size_t)s->n_materials);

@@ -1608,6 +1608,95 @@ static int validate_primitives(const RtScene *s) {
   return RT_OK;
 }
 
+// Wide nodes: up to four children per node, made from the grid nodes by opening, largest box first, the internal children of a
+// node until four boxes are held (or only leaves are left).
+// Measured (one MI355X): the walk fetches half as many node records on them (100 000 triangles: 14.7 -> 7.0 per ray) but the
+// same bytes, and is no faster while the binary records stay in the caches (k_extend 633 -> 690 ms; 2 M triangles 1115 -> 1180 ms);
+// on a 10 M-triangle soup, whose 320 MB of node records do not, it is 6 % faster.  Hence: made for trees above 256 MB of binary
+// records, RT_HIP_WIDE=1 / 0 forces them on / off.
+static bool wide_nodes_wanted(size_t n_internal) {
+  const char *wide_env = getenv("RT_HIP_WIDE");
+  return wide_env ? atoi(wide_env) != 0 : n_internal * sizeof(DevNodeQ) > ((size_t)256 << 20);
+}
+// `nodes_q`: the binary grid records, internal children named by their index in it; `root`: the root's index.  Leaves `nodes_w`
+// empty when a lane's stack could need more entries on them than the walk provides for.
+static void collapse_to_wide(const std::vector<DevNodeQ> &nodes_q, uint32_t root, const double grid_step[3], std::vector<DevNodeW> &nodes_w,
+                             int32_t &stack_depth_w) {
+  struct Child {
+    uint16_t mn[3], mx[3];
+    uint32_t ref;
+  };
+  struct Item {
+    uint32_t bin, wide;
+  };
+  auto left_of = [](const DevNodeQ &q) { return Child{{q.lmin[0], q.lmin[1], q.lmin[2]}, {q.lmax[0], q.lmax[1], q.lmax[2]}, q.left}; };
+  auto right_of = [](const DevNodeQ &q) { return Child{{q.rmin[0], q.rmin[1], q.rmin[2]}, {q.rmax[0], q.rmax[1], q.rmax[2]}, q.right}; };
+  auto area_of = [&](const Child &c) {
+    double dx = (c.mx[0] - c.mn[0]) * grid_step[0], dy = (c.mx[1] - c.mn[1]) * grid_step[1], dz = (c.mx[2] - c.mn[2]) * grid_step[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  nodes_w.clear();
+  nodes_w.reserve(nodes_q.size() / 2 + 1);
+  std::vector<Item> todo;
+  nodes_w.emplace_back();
+  todo.push_back({root, 0u});
+  while (!todo.empty()) {
+    Item it = todo.back();
+    todo.pop_back();
+    Child ch[4];
+    int n = 2;
+    ch[0] = left_of(nodes_q[it.bin]);
+    ch[1] = right_of(nodes_q[it.bin]);
+    while (n < 4) {
+      int best = -1;
+      double best_area = -1.0;
+      for (int i = 0; i < n; i++)
+        if (!(ch[i].ref & kRefLeaf)) {
+          double a = area_of(ch[i]);
+          if (a > best_area) best_area = a, best = i;
+        }
+      if (best < 0) break;
+      const DevNodeQ &open = nodes_q[ch[best].ref];
+      ch[best] = left_of(open);
+      ch[n++] = right_of(open);
+    }
+    DevNodeW w;
+    for (int i = 0; i < 4; i++) {
+      if (i >= n) {
+        w.px[i] = w.py[i] = w.pz[i] = 0;
+        w.child[i] = kRefNone;
+        continue;
+      }
+      w.px[i] = (uint32_t)ch[i].mn[0] | ((uint32_t)ch[i].mx[0] << 16);
+      w.py[i] = (uint32_t)ch[i].mn[1] | ((uint32_t)ch[i].mx[1] << 16);
+      w.pz[i] = (uint32_t)ch[i].mn[2] | ((uint32_t)ch[i].mx[2] << 16);
+      if (ch[i].ref & kRefLeaf) {
+        w.child[i] = ch[i].ref;
+      } else {
+        w.child[i] = (uint32_t)nodes_w.size();
+        todo.push_back({ch[i].ref, (uint32_t)nodes_w.size()});
+        nodes_w.emplace_back();
+      }
+    }
+    nodes_w[it.wide] = w;
+  }
+  // stack entries a lane can need below a node: all but one of its children pushed, then the deepest child
+  // (children are stored after their parent, so one backward pass does it)
+  std::vector<int32_t> need(nodes_w.size(), 0);
+  for (size_t i = nodes_w.size(); i-- > 0;) {
+    int32_t deepest = 0, k = 0;
+    for (int c = 0; c < 4; c++) {
+      uint32_t r = nodes_w[i].child[c];
+      if (r == kRefNone) continue;
+      k++;
+      if (!(r & kRefLeaf)) deepest = std::max(deepest, need[r]);
+    }
+    need[i] = deepest + k - 1;
+  }
+  stack_depth_w = std::max(need[0], 1);
+  if (stack_depth_w > kMaxStackDepth + kWideLdsLevels) nodes_w.clear(), stack_depth_w = 1;
+}
+
 // Global-memory part of the traversal stacks of a tree higher than the LDS part holds: [level][wave][lane].
 static int alloc_stack_spill(RtSceneHandle *h) {
   h->dev.stack_spill = nullptr;
@@ -2009,90 +2098,12 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
       if (!(total_growth <= 1.10 * total_size)) nodes_q.clear();
     }
   }
-  // ---- wide nodes: up to four children per node, made from the grid nodes by opening, largest box first, the
-  // internal children of a node until four boxes are held (or only leaves are left)
+  // ---- wide nodes (collapse_to_wide above)
   std::vector<DevNodeW> nodes_w;
   int32_t stack_depth_w = 1;
-  // Measured (one MI355X): the walk fetches half as many node records on them (100 000 triangles: 14.7 -> 7.0 per ray) but the
-  // same bytes, and is no faster while the binary records stay in the caches (k_extend 633 -> 690 ms; 2 M triangles 1115 -> 1180 ms);
-  // on a 10 M-triangle soup, whose 320 MB of node records do not, it is 6 % faster.  Hence: made for trees above 256 MB of binary
-  // records, RT_HIP_WIDE=1 / 0 forces them on / off.
-  const char *wide_env = getenv("RT_HIP_WIDE");
-  const bool wide_wanted = wide_env ? atoi(wide_env) != 0 : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)256 << 20);
-  if (!nodes_q.empty() && !s->nodes[0].is_leaf && wide_wanted) {
-    struct Child {
-      uint16_t mn[3], mx[3];
-      uint32_t ref;
-    };
-    struct Item {
-      uint32_t bin, wide;
-    };
-    auto left_of = [](const DevNodeQ &q) { return Child{{q.lmin[0], q.lmin[1], q.lmin[2]}, {q.lmax[0], q.lmax[1], q.lmax[2]}, q.left}; };
-    auto right_of = [](const DevNodeQ &q) { return Child{{q.rmin[0], q.rmin[1], q.rmin[2]}, {q.rmax[0], q.rmax[1], q.rmax[2]}, q.right}; };
-    auto area_of = [&](const Child &c) {
-      double dx = (c.mx[0] - c.mn[0]) * grid_step[0], dy = (c.mx[1] - c.mn[1]) * grid_step[1], dz = (c.mx[2] - c.mn[2]) * grid_step[2];
-      return dx * dy + dy * dz + dz * dx;
-    };
-    nodes_w.reserve((size_t)n_internal / 2 + 1);
-    std::vector<Item> todo;
-    nodes_w.emplace_back();
-    todo.push_back({(uint32_t)internal_index[0], 0u});
-    while (!todo.empty()) {
-      Item it = todo.back();
-      todo.pop_back();
-      Child ch[4];
-      int n = 2;
-      ch[0] = left_of(nodes_q[it.bin]);
-      ch[1] = right_of(nodes_q[it.bin]);
-      while (n < 4) {
-        int best = -1;
-        double best_area = -1.0;
-        for (int i = 0; i < n; i++)
-          if (!(ch[i].ref & kRefLeaf)) {
-            double a = area_of(ch[i]);
-            if (a > best_area) best_area = a, best = i;
-          }
-        if (best < 0) break;
-        const DevNodeQ &open = nodes_q[ch[best].ref];
-        ch[best] = left_of(open);
-        ch[n++] = right_of(open);
-      }
-      DevNodeW w;
-      for (int i = 0; i < 4; i++) {
-        if (i >= n) {
-          w.px[i] = w.py[i] = w.pz[i] = 0;
-          w.child[i] = kRefNone;
-          continue;
-        }
-        w.px[i] = (uint32_t)ch[i].mn[0] | ((uint32_t)ch[i].mx[0] << 16);
-        w.py[i] = (uint32_t)ch[i].mn[1] | ((uint32_t)ch[i].mx[1] << 16);
-        w.pz[i] = (uint32_t)ch[i].mn[2] | ((uint32_t)ch[i].mx[2] << 16);
-        if (ch[i].ref & kRefLeaf) {
-          w.child[i] = ch[i].ref;
-        } else {
-          w.child[i] = (uint32_t)nodes_w.size();
-          todo.push_back({ch[i].ref, (uint32_t)nodes_w.size()});
-          nodes_w.emplace_back();
-        }
-      }
-      nodes_w[it.wide] = w;
-    }
-    // stack entries a lane can need below a node: all but one of its children pushed, then the deepest child
-    // (children are stored after their parent, so one backward pass does it)
-    std::vector<int32_t> need(nodes_w.size(), 0);
-    for (size_t i = nodes_w.size(); i-- > 0;) {
-      int32_t deepest = 0, k = 0;
-      for (int c = 0; c < 4; c++) {
-        uint32_t r = nodes_w[i].child[c];
-        if (r == kRefNone) continue;
-        k++;
-        if (!(r & kRefLeaf)) deepest = std::max(deepest, need[r]);
-      }
-      need[i] = deepest + k - 1;
-    }
-    stack_depth_w = std::max(need[0], 1);
+  if (!nodes_q.empty() && !s->nodes[0].is_leaf && wide_nodes_wanted((size_t)n_internal)) {
+    collapse_to_wide(nodes_q, (uint32_t)internal_index[0], grid_step, nodes_w, stack_depth_w);
     if (verbose) fprintf(stderr, "rt_hip upload: %zu wide nodes for %d binary ones, stack need %d\n", nodes_w.size(), n_internal, stack_depth_w);
-    if (stack_depth_w > kMaxStackDepth + kWideLdsLevels) nodes_w.clear();
   }
   std::vector<DevTriangle> tris((size_t)s->n_triangles);
   std::vector<DevTriShade> tri_shade((size_t)s->n_triangles);

@@ -92,6 +92,33 @@ def test_device_built_tree_gives_the_oracles_hits(which, tmp_scene_dir):
     dev.close()
 
 
+def test_device_built_tree_with_wide_nodes_and_padded_triangle_records(monkeypatch, tmp_scene_dir):
+    """What scenes beyond the caches get (forced here by RT_HIP_WIDE / RT_HIP_TRI_PAD): the device-built binary records collapsed
+    to four-wide ones, triangle records one per 128-byte line.  Same hits, same image as on the plain device-built tree."""
+    ri = knot_scene(tmp_scene_dir, 20000, 48, 48, 8, 2, 2)
+    o, d = random_rays(150_000, seed=73)
+    results = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("RT_HIP_WIDE", forced)
+        monkeypatch.setenv("RT_HIP_TRI_PAD", forced)
+        dev = ResidentScene(ri.scene, 0, build_on_device=True)
+        p, t = dev.trace_rays(o, d)
+        out, st = dev.render(ri.config.copy())
+        counted = ri.config.copy()
+        counted.flags = abi.RT_FLAG_COUNT_VISITS
+        _, sc = dev.render(counted)
+        nodes = dev.download_tree()
+        results.append((p, t, out["linear"], int(st.rays), sc.node_visits / sc.rays_traced, nodes))
+        dev.close()
+    (p0, t0, l0, r0, v0, n0), (p1, t1, l1, r1, v1, n1) = results
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and np.array_equal(l0, l1) and r0 == r1
+    assert v1 < 0.7 * v0                                          # the wide records really were walked
+    assert bytes(n0) == bytes(n1)                                 # the padded records download as the same tree
+    twin = _scene_with_nodes(ri, n1)
+    po, to = oracle.trace_rays(C.byref(twin), o, d)
+    assert np.array_equal(p1, po) and np.array_equal(t1, to)
+
+
 def test_device_built_tree_against_the_host_built_one(tmp_scene_dir):
     """Same closest hits as with the reference-order tree: t exact; ids differ only where two primitives are hit at
     exactly the same t (the duplicated wall triangles of the reference's scene).  Images agree within noise."""

@@ -20,12 +20,16 @@ def main():
     ap.add_argument("--triangles", type=int, default=2_000_000)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-batches", type=int, default=64)
+    ap.add_argument("--soup", action="store_true", help="the triangle soup of BASELINE's largest configuration instead of the mesh (batches of 16, up to 4)")
     ap.add_argument("--no-count", action="store_true", help="time the production kernels (the visit-counting ones run at four waves per SIMD)")
     args = ap.parse_args()
     from raytracer_amd import RenderIntegrator, abi, scenes
     from raytracer_amd.integrator import ResidentScene
     d = os.path.join(tempfile.gettempdir(), f"rt_build_timing_{os.getuid()}")
-    scene_path, config_path = scenes.materialize_c3(d, args.triangles, args.size, args.size, batch=16, max_batches=args.max_batches, min_batches=2)
+    if args.soup:
+        scene_path, config_path = scenes.materialize_soup(d, args.triangles, args.size, args.size * 9 // 16, batch=16, max_batches=4, min_batches=2)
+    else:
+        scene_path, config_path = scenes.materialize_c3(d, args.triangles, args.size, args.size, batch=16, max_batches=args.max_batches, min_batches=2)
     out = {"triangles": args.triangles, "image": [args.size, args.size]}
     # host path: load + expand + reference-order SAH build, upload, render
     t0 = time.perf_counter()
