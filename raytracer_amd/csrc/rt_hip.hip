@@ -1626,27 +1626,19 @@ static void collapse_to_wide(const std::vector<DevNodeQ> &nodes_q, uint32_t root
     uint16_t mn[3], mx[3];
     uint32_t ref;
   };
-  struct Item {
-    uint32_t bin, wide;
-  };
   auto left_of = [](const DevNodeQ &q) { return Child{{q.lmin[0], q.lmin[1], q.lmin[2]}, {q.lmax[0], q.lmax[1], q.lmax[2]}, q.left}; };
   auto right_of = [](const DevNodeQ &q) { return Child{{q.rmin[0], q.rmin[1], q.rmin[2]}, {q.rmax[0], q.rmax[1], q.rmax[2]}, q.right}; };
   auto area_of = [&](const Child &c) {
     double dx = (c.mx[0] - c.mn[0]) * grid_step[0], dy = (c.mx[1] - c.mn[1]) * grid_step[1], dz = (c.mx[2] - c.mn[2]) * grid_step[2];
     return dx * dy + dy * dz + dz * dx;
   };
-  nodes_w.clear();
-  nodes_w.reserve(nodes_q.size() / 2 + 1);
-  std::vector<Item> todo;
-  nodes_w.emplace_back();
-  todo.push_back({root, 0u});
-  while (!todo.empty()) {
-    Item it = todo.back();
-    todo.pop_back();
+  // the wide node that stands for binary node `bin`: boxes and leaf refs filled in, internal children left as kRefNone with
+  // the binary node each stands for in `below`
+  auto open_node = [&](uint32_t bin, DevNodeW &w, uint32_t below[4]) {
     Child ch[4];
     int n = 2;
-    ch[0] = left_of(nodes_q[it.bin]);
-    ch[1] = right_of(nodes_q[it.bin]);
+    ch[0] = left_of(nodes_q[bin]);
+    ch[1] = right_of(nodes_q[bin]);
     while (n < 4) {
       int best = -1;
       double best_area = -1.0;
@@ -1660,8 +1652,8 @@ static void collapse_to_wide(const std::vector<DevNodeQ> &nodes_q, uint32_t root
       ch[best] = left_of(open);
       ch[n++] = right_of(open);
     }
-    DevNodeW w;
     for (int i = 0; i < 4; i++) {
+      below[i] = kRefNone;
       if (i >= n) {
         w.px[i] = w.py[i] = w.pz[i] = 0;
         w.child[i] = kRefNone;
@@ -1670,15 +1662,89 @@ static void collapse_to_wide(const std::vector<DevNodeQ> &nodes_q, uint32_t root
       w.px[i] = (uint32_t)ch[i].mn[0] | ((uint32_t)ch[i].mx[0] << 16);
       w.py[i] = (uint32_t)ch[i].mn[1] | ((uint32_t)ch[i].mx[1] << 16);
       w.pz[i] = (uint32_t)ch[i].mn[2] | ((uint32_t)ch[i].mx[2] << 16);
-      if (ch[i].ref & kRefLeaf) {
-        w.child[i] = ch[i].ref;
-      } else {
-        w.child[i] = (uint32_t)nodes_w.size();
-        todo.push_back({ch[i].ref, (uint32_t)nodes_w.size()});
-        nodes_w.emplace_back();
-      }
+      w.child[i] = (ch[i].ref & kRefLeaf) ? ch[i].ref : kRefNone;
+      if (!(ch[i].ref & kRefLeaf)) below[i] = ch[i].ref;
     }
-    nodes_w[it.wide] = w;
+  };
+  struct Item {
+    uint32_t bin, wide;
+  };
+  // everything below binary node `bin`, depth-first; out[0] stands for `bin`, internal children are named by their index in `out`
+  auto collapse_subtree = [&](uint32_t bin, std::vector<DevNodeW> &out) {
+    std::vector<Item> todo;
+    out.emplace_back();
+    todo.push_back({bin, 0u});
+    while (!todo.empty()) {
+      Item it = todo.back();
+      todo.pop_back();
+      DevNodeW w;
+      uint32_t below[4];
+      open_node(it.bin, w, below);
+      for (int i = 0; i < 4; i++)
+        if (below[i] != kRefNone) {
+          w.child[i] = (uint32_t)out.size();
+          todo.push_back({below[i], (uint32_t)out.size()});
+          out.emplace_back();
+        }
+      out[it.wide] = w;
+    }
+  };
+  nodes_w.clear();
+  const int threads = upload_threads();
+  if (threads <= 1 || nodes_q.size() < ((size_t)1 << 18)) {
+    nodes_w.reserve(nodes_q.size() / 2 + 1);
+    collapse_subtree(root, nodes_w);
+  } else {
+    // the top of the tree breadth-first until there are subtrees enough to share out among the threads; then every subtree
+    // on its own, and the pieces one after the other
+    struct Pending {
+      uint32_t bin, parent, slot;  // the wide node `parent` names it in child[slot] once its index is known
+    };
+    std::vector<Pending> fifo;
+    size_t head = 0;
+    fifo.push_back({root, kRefNone, 0u});
+    const size_t want = (size_t)threads * 16;
+    while (head < fifo.size() && fifo.size() - head < want) {
+      Pending p = fifo[head++];
+      const uint32_t me = (uint32_t)nodes_w.size();
+      if (p.parent != kRefNone) nodes_w[p.parent].child[p.slot] = me;
+      DevNodeW w;
+      uint32_t below[4];
+      open_node(p.bin, w, below);
+      nodes_w.push_back(w);
+      for (uint32_t i = 0; i < 4; i++)
+        if (below[i] != kRefNone) fifo.push_back({below[i], me, i});
+    }
+    const size_t n_sub = fifo.size() - head;
+    std::vector<std::vector<DevNodeW>> sub(n_sub);
+    std::atomic<size_t> next{0};
+    std::vector<std::exception_ptr> failures((size_t)threads);
+    std::vector<std::thread> pool;
+    for (int c = 0; c < threads; c++)
+      pool.emplace_back([&, c] {
+        try {
+          for (size_t k; (k = next.fetch_add(1)) < n_sub;) collapse_subtree(fifo[head + k].bin, sub[k]);
+        } catch (...) {
+          failures[(size_t)c] = std::current_exception();
+        }
+      });
+    for (auto &t : pool) t.join();
+    for (auto &f : failures)
+      if (f) std::rethrow_exception(f);
+    size_t total = nodes_w.size();
+    for (const auto &v : sub) total += v.size();
+    nodes_w.reserve(total);
+    for (size_t k = 0; k < n_sub; k++) {
+      const uint32_t offset = (uint32_t)nodes_w.size();
+      const Pending &p = fifo[head + k];
+      nodes_w[p.parent].child[p.slot] = offset;
+      for (DevNodeW w : sub[k]) {
+        for (int i = 0; i < 4; i++)
+          if (!(w.child[i] & kRefLeaf)) w.child[i] += offset;  // (an unused slot, kRefNone, carries the leaf bit)
+        nodes_w.push_back(w);
+      }
+      std::vector<DevNodeW>().swap(sub[k]);
+    }
   }
   // stack entries a lane can need below a node: all but one of its children pushed, then the deepest child
   // (children are stored after their parent, so one backward pass does it)

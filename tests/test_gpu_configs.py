@@ -162,3 +162,39 @@ def test_c4_shape_is_shard_independent(big):
     shard = parallel.shard_config(cfg, 5, 8)
     o, s = res.render(shard)
     assert np.array_equal(o["linear"], out["linear"][5::8]) and np.array_equal(o["samples"], out["samples"][5::8])
+
+
+def test_c4_shape_on_wide_nodes_host_built_and_device_built(big, monkeypatch):
+    """2.2 M internal nodes: the four-wide records (forced: by default only trees beyond the caches get them) are collapsed subtree
+    by subtree on several host threads, from the uploaded tree and from the tree built on the device.  Hits and image rows as on
+    the binary records."""
+    from raytracer_amd.integrator import ResidentScene
+    ri, res, cfg, out, st = big
+    monkeypatch.setenv("RT_HIP_WIDE", "1")
+    every = cfg.copy()
+    every.row_first, every.row_stride = 5, 32
+    p0, t0 = res.primary_hits(every)
+    rng = np.random.RandomState(11)
+    o = rng.uniform(5.0, 550.0, size=(300_000, 3))
+    d = rng.normal(size=(300_000, 3))
+    r0, s0 = res.trace_rays(o, d)
+    wide = ResidentScene(ri.scene, 0)
+    p1, t1 = wide.primary_hits(every)
+    r1, s1 = wide.trace_rays(o, d)
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and np.array_equal(r0, r1) and np.array_equal(s0, s1)
+    shard = parallel.shard_config(cfg, 3, 64)
+    a, sa = wide.render(shard)
+    assert np.array_equal(a["linear"], out["linear"][3::64]) and np.array_equal(a["samples"], out["samples"][3::64])
+    counted = shard.copy()
+    counted.flags = abi.RT_FLAG_COUNT_VISITS
+    _, sw = wide.render(counted)
+    _, sb = res.render(counted)
+    assert sw.node_visits / sw.rays_traced < 0.7 * sb.node_visits / sb.rays_traced
+    wide.close()
+    dev = ResidentScene(ri.scene, 0, build_on_device=True)
+    r2, s2 = dev.trace_rays(o, d)
+    assert np.array_equal(s0, s2)                                   # the same closest hits; ids may differ at exact ties only
+    assert (r0 != r2).mean() < 0.2
+    _, sd = dev.render(counted)
+    assert sd.node_visits / sd.rays_traced < 0.7 * sb.node_visits / sb.rays_traced
+    dev.close()
