@@ -82,6 +82,18 @@ def test_gather_two_ranks_gloo(tmp_path, height, block):
     assert f"OK {height}" in out.stdout
 
 
+def test_gather_eight_ranks_gloo_with_uneven_shards(tmp_path):
+    """The largest rank count a node has: 21 rows over 8 ranks (three rows on some ranks, two on others, padded for the collective)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(script), ROOT, "21", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK 21" in out.stdout
+
+
 def test_oracle_renders_a_block_shard_as_the_rows_of_the_whole_image():
     """RtConfig.row_block on the CPU oracle (per-path streams: a shard's pixels do not depend on the sharding)."""
     from helpers import c1
