@@ -41,6 +41,24 @@ def test_noalloc_queries_equal_trace_rays_on_two_calls_in_a_row(tmp_scene_dir):
         assert (want_id >= 0).mean() > 0.5 or n == 1
 
 
+def test_noalloc_on_a_tree_whose_stacks_leave_lds(monkeypatch, tmp_scene_dir):
+    """Trees too high for on-chip stacks move blocks of stack entries to a buffer in device memory: it belongs to the scene
+    (allocated at set-up), so the query still allocates nothing.  Forced here on a tree of moderate height."""
+    torch = pytest.importorskip("torch")
+    from raytracer_amd.integrator import ResidentScene
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    assert ri.bvh_depth() > 16
+    plain = ri.resident(0)  # uploaded before the variable is set: every stack in LDS
+    monkeypatch.setenv("RT_HIP_SPILL_ABOVE", "16")
+    res = ResidentScene(ri.scene, 0)
+    for n, seed in ((100_000, 44), (5_000, 45)):
+        o, d = random_rays(n, seed=seed)
+        want_id, want_t = plain.trace_rays(o, d)
+        got_id, got_t = _device_call(torch, res, o, d)
+        assert np.array_equal(got_id, want_id) and np.array_equal(got_t, want_t)
+    res.close()
+
+
 def test_noalloc_follows_the_reference_visit_rule_where_the_scene_needs_it():
     """A scene with quads that stick out of their boxes is walked in two passes: both sets of claim counters are used."""
     torch = pytest.importorskip("torch")
