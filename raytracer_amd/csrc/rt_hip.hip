@@ -38,6 +38,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1548,14 +1549,21 @@ static void parallel_for(size_t n, F &&fn) {  // fn(begin, end) over [0, n); a w
   }
   std::vector<std::thread> pool;
   std::vector<std::exception_ptr> failures((size_t)threads);
-  for (int c = 0; c < threads; c++)
-    pool.emplace_back([&, c] {
-      try {
-        fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
-      } catch (...) {
-        failures[(size_t)c] = std::current_exception();
-      }
-    });
+  auto chunk = [&](int c) {
+    try {
+      fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
+    } catch (...) {
+      failures[(size_t)c] = std::current_exception();
+    }
+  };
+  pool.reserve((size_t)threads);
+  for (int c = 0; c < threads; c++) {
+    try {
+      pool.emplace_back(chunk, c);
+    } catch (const std::system_error &) {  // no more threads to be had: the caller does this share itself
+      chunk(c);
+    }
+  }
   for (auto &t : pool) t.join();
   for (auto &f : failures)
     if (f) std::rethrow_exception(f);
@@ -1720,14 +1728,22 @@ static void collapse_to_wide(const std::vector<DevNodeQ> &nodes_q, uint32_t root
     std::atomic<size_t> next{0};
     std::vector<std::exception_ptr> failures((size_t)threads);
     std::vector<std::thread> pool;
-    for (int c = 0; c < threads; c++)
-      pool.emplace_back([&, c] {
-        try {
-          for (size_t k; (k = next.fetch_add(1)) < n_sub;) collapse_subtree(fifo[head + k].bin, sub[k]);
-        } catch (...) {
-          failures[(size_t)c] = std::current_exception();
-        }
-      });
+    auto worker = [&](int c) {
+      try {
+        for (size_t k; (k = next.fetch_add(1)) < n_sub;) collapse_subtree(fifo[head + k].bin, sub[k]);
+      } catch (...) {
+        failures[(size_t)c] = std::current_exception();
+      }
+    };
+    pool.reserve((size_t)threads);
+    for (int c = 1; c < threads; c++) {
+      try {
+        pool.emplace_back(worker, c);
+      } catch (const std::system_error &) {  // no more threads to be had: the ones there are share the work
+        break;
+      }
+    }
+    worker(0);
     for (auto &t : pool) t.join();
     for (auto &f : failures)
       if (f) std::rethrow_exception(f);
