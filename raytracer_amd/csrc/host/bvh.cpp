@@ -11,6 +11,7 @@
 #include <exception>
 #include <limits>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 #include "scene.hpp"
@@ -67,19 +68,22 @@ void run_chunks(int n_chunks, F &&fn) {
   }
   std::vector<std::thread> pool;
   std::vector<std::exception_ptr> failures((size_t)n_chunks);
-  for (int c = 0; c + 1 < n_chunks; c++)
-    pool.emplace_back([&, c] {
-      try {
-        fn(c);
-      } catch (...) {
-        failures[(size_t)c] = std::current_exception();
-      }
-    });
-  try {
-    fn(n_chunks - 1);
-  } catch (...) {
-    failures[(size_t)n_chunks - 1] = std::current_exception();
+  auto chunk = [&](int c) {
+    try {
+      fn(c);
+    } catch (...) {
+      failures[(size_t)c] = std::current_exception();
+    }
+  };
+  pool.reserve((size_t)n_chunks);
+  for (int c = 0; c + 1 < n_chunks; c++) {
+    try {
+      pool.emplace_back(chunk, c);
+    } catch (const std::system_error &) {  // no more threads to be had: the caller does this chunk itself
+      chunk(c);
+    }
   }
+  chunk(n_chunks - 1);
   for (auto &t : pool) t.join();
   for (auto &f : failures)
     if (f) std::rethrow_exception(f);
@@ -300,20 +304,26 @@ struct Builder {
     const size_t mid = lo + n_left, right_pos = pos + 2 * n_left;
     if (n_left >= kParallelSubtree && spare_threads.fetch_sub(1, std::memory_order_relaxed) > 0) {
       std::exception_ptr failure;
-      std::thread worker([&, this] {
+      auto left = [&, this] {
         try {
           build(lo, mid, pos + 1, depth + 1);
         } catch (...) {
           failure = std::current_exception();
         }
-      });
+      };
+      std::thread worker;
+      try {
+        worker = std::thread(left);
+      } catch (const std::system_error &) {  // no more threads to be had: both halves on this one
+        left();
+      }
       std::exception_ptr mine;
       try {
         build(mid, hi, right_pos, depth + 1);
       } catch (...) {
         mine = std::current_exception();
       }
-      worker.join();
+      if (worker.joinable()) worker.join();
       spare_threads.fetch_add(1, std::memory_order_relaxed);
       if (mine) std::rethrow_exception(mine);
       if (failure) std::rethrow_exception(failure);

@@ -14,6 +14,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -150,24 +151,36 @@ class RenderIntegrator {
     std::vector<std::vector<double>> px((size_t)n), heat((size_t)n);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
+    pool.reserve((size_t)n);
     for (int r = 0; r < n; r++) {
-      pool.emplace_back([&, r] {
-        if (!shard_scenes[(size_t)r] && rt_hip_scene_upload(&pod, want[(size_t)r], &shard_scenes[(size_t)r]) != RT_OK) {
-          errors[(size_t)r] = rt_hip_last_error();
-          return;
+      auto shard = [&, r] {
+        try {
+          if (!shard_scenes[(size_t)r] && rt_hip_scene_upload(&pod, want[(size_t)r], &shard_scenes[(size_t)r]) != RT_OK) {
+            errors[(size_t)r] = rt_hip_last_error();
+            return;
+          }
+          RtConfig cfg = pod_config;
+          cfg.row_first = r;
+          cfg.row_stride = n;
+          size_t rows = (size_t)((H - r + n - 1) / n);
+          px[(size_t)r].resize(rows * (size_t)W * 3);
+          heat[(size_t)r].resize(rows * (size_t)W * 3);
+          RtImage img{};
+          img.pixels = px[(size_t)r].data();
+          img.sample_pixels = heat[(size_t)r].data();
+          img.memory = RT_MEM_HOST;
+          if (rt_hip_render_resident(shard_scenes[(size_t)r], &cfg, &img, &part[(size_t)r]) != RT_OK) errors[(size_t)r] = rt_hip_last_error();
+        } catch (const std::exception &e) {  // nothing may leave a worker thread
+          errors[(size_t)r] = e.what();
+        } catch (...) {
+          errors[(size_t)r] = "unknown failure";
         }
-        RtConfig cfg = pod_config;
-        cfg.row_first = r;
-        cfg.row_stride = n;
-        size_t rows = (size_t)((H - r + n - 1) / n);
-        px[(size_t)r].resize(rows * (size_t)W * 3);
-        heat[(size_t)r].resize(rows * (size_t)W * 3);
-        RtImage img{};
-        img.pixels = px[(size_t)r].data();
-        img.sample_pixels = heat[(size_t)r].data();
-        img.memory = RT_MEM_HOST;
-        if (rt_hip_render_resident(shard_scenes[(size_t)r], &cfg, &img, &part[(size_t)r]) != RT_OK) errors[(size_t)r] = rt_hip_last_error();
-      });
+      };
+      try {
+        pool.emplace_back(shard);
+      } catch (const std::system_error &) {  // no more threads to be had: this shard on the caller's
+        shard();
+      }
     }
     for (std::thread &t : pool) t.join();
     for (int r = 0; r < n; r++)

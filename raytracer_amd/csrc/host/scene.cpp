@@ -11,6 +11,7 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 namespace rt {
@@ -317,14 +318,21 @@ static void parallel_ranges(size_t n, int threads, size_t min_items, F &&fn) {  
   }
   std::vector<std::thread> pool;
   std::vector<std::exception_ptr> failures((size_t)threads);
-  for (int c = 0; c < threads; c++)
-    pool.emplace_back([&, c] {
-      try {
-        fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
-      } catch (...) {
-        failures[(size_t)c] = std::current_exception();
-      }
-    });
+  auto chunk = [&](int c) {
+    try {
+      fn(n * (size_t)c / (size_t)threads, n * (size_t)(c + 1) / (size_t)threads);
+    } catch (...) {
+      failures[(size_t)c] = std::current_exception();
+    }
+  };
+  pool.reserve((size_t)threads);
+  for (int c = 0; c < threads; c++) {
+    try {
+      pool.emplace_back(chunk, c);
+    } catch (const std::system_error &) {  // no more threads to be had: the caller does this share itself
+      chunk(c);
+    }
+  }
   for (auto &t : pool) t.join();
   for (auto &f : failures)
     if (f) std::rethrow_exception(f);
