@@ -721,15 +721,19 @@ struct PathResults {
 //    "does the path go on?";
 //  * a path that ends stores its result at once; wave64 compaction of the survivors: ballot, prefix popcount, one atomic per wave.
 constexpr int kShadeCategories = 4;
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256
+#endif
+constexpr int kShadeBlock = RT_SHADE_BLOCK, kShadeWaves = kShadeBlock / 64;  // paths a workgroup sorts together
 __attribute__((amdgpu_waves_per_eu(4, 4)))
-__global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
                                                        uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
   constexpr int kLdsMaterials = 64;
   __shared__ DevMaterial lds_materials[kLdsMaterials];
-  __shared__ double lds_f64[13][256];  // point, normal, throughput, direction (3 each), material parameter
-  __shared__ uint64_t lds_rng[256];
-  __shared__ uint32_t lds_pid[256], lds_bits[256];
-  __shared__ uint32_t lds_counts[kShadeCategories][4];  // continuing paths per category and wave
+  __shared__ double lds_f64[13][kShadeBlock];  // point, normal, throughput, direction (3 each), material parameter
+  __shared__ uint64_t lds_rng[kShadeBlock];
+  __shared__ uint32_t lds_pid[kShadeBlock], lds_bits[kShadeBlock];
+  __shared__ uint32_t lds_counts[kShadeCategories][kShadeWaves];  // continuing paths per category and wave
   const bool staged = sc.n_materials <= kLdsMaterials;
   if (staged) {
     const uint32_t words = (uint32_t)sc.n_materials * (uint32_t)(sizeof(DevMaterial) / 4);
@@ -739,13 +743,13 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
   }
   const uint32_t region = blockIdx.x % kRegions;
   const uint32_t n = count_ptr[region * kCounterStride];
-  const uint32_t stride = (gridDim.x / kRegions) * 256u;
-  const uint32_t n_round = (n + 255u) & ~255u;  // whole workgroups: every thread reaches every barrier
+  const uint32_t stride = (gridDim.x / kRegions) * (uint32_t)kShadeBlock;
+  const uint32_t n_round = (n + (uint32_t)kShadeBlock - 1u) / (uint32_t)kShadeBlock * (uint32_t)kShadeBlock;  // whole workgroups: every thread reaches every barrier
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const uint32_t in0 = region * q.cap, out0 = region * out.cap;
   uint32_t *out_counter = out_count + region * kCounterStride;
-  const uint32_t jj0 = (blockIdx.x / kRegions) * 256u + threadIdx.x;
+  const uint32_t jj0 = (blockIdx.x / kRegions) * (uint32_t)kShadeBlock + threadIdx.x;
   uint32_t ref_ahead = jj0 < n ? hits.ref[in0 + jj0] : kRefNone;
   for (uint32_t jj = jj0; jj - threadIdx.x < n_round; jj += stride) {
     const uint32_t j = in0 + jj;
@@ -836,7 +840,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
 #pragma unroll
       for (int c = 0; c < kShadeCategories; c++)
 #pragma unroll
-        for (uint32_t w = 0; w < 4; w++) {
+        for (uint32_t w = 0; w < (uint32_t)kShadeWaves; w++) {
           uint32_t cnt = lds_counts[c][w];
           if (c < cat || (c == cat && w < wave)) pos += cnt;
         }
@@ -856,7 +860,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathQueue q, const u
 #pragma unroll
     for (int c = 0; c < kShadeCategories; c++)
 #pragma unroll
-      for (uint32_t w = 0; w < 4; w++) total += lds_counts[c][w];
+      for (uint32_t w = 0; w < (uint32_t)kShadeWaves; w++) total += lds_counts[c][w];
     // ---- phase B: thread i samples the i-th continuing path of the workgroup
     const uint32_t i = threadIdx.x;
     bool alive = i < total;
@@ -2497,7 +2501,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       // k_shade: a whole number of workgroups per region, and many more of them than fit the
       // chip at once -- short workgroups even out the uneven cost of the material branches
       static const int shade_blocks = getenv("RT_HIP_SHADE_BLOCKS") ? std::max((int)kRegions, atoi(getenv("RT_HIP_SHADE_BLOCKS")) / (int)kRegions * (int)kRegions) : 256 * 64;
-      int g_shade = (int)std::min<int64_t>(shade_blocks, (np / block / kRegions + 1) * kRegions);
+      int g_shade = (int)std::min<int64_t>(shade_blocks, (np / kShadeBlock / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
       if (S <= kGenMaxShared) {
         const int spb = std::max(1, std::min(block, kGenMaxShared) / S);  // pixel slots per workgroup: about one (slot, sample) per lane
@@ -2514,8 +2518,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         LAUNCHED("k_extend");
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1, k));
-        static_assert(block == 256, "k_shade sorts per workgroup of four waves");
-        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(block), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
+        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kShadeBlock), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
                            results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
         LAUNCHED("k_shade");
         HIP_TRY(mark_end());
