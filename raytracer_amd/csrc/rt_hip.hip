@@ -592,7 +592,7 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   const bool spill = extend_spills(sc, quirk);
   if (quirk) {
     if (counted) RT_LAUNCH_EXTEND(true, true, false, false, 4);
-    else RT_LAUNCH_EXTEND(true, false, false, false, 4);
+    else RT_LAUNCH_EXTEND(true, false, false, false, 5);  // 96 registers, none in scratch (README scene, every ray by this rule: 1933 ms at four waves, 1697 at five, 1718 at six with 60 bytes of scratch)
   } else if (sc.nodes_w) {
     static const int wide_waves = getenv("RT_HIP_WIDE_WAVES") ? atoi(getenv("RT_HIP_WIDE_WAVES")) : 5;  // 100 000 triangles: 690 ms at five waves per SIMD, 719 at six
 #define RT_LAUNCH_WIDE(C, S, W) hipLaunchKernelGGL((k_extend<false, C, true, S, W, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
