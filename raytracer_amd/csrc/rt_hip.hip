@@ -613,7 +613,9 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
     else RT_LAUNCH_EXTEND(false, false, true, false, 5);
   } else {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, false, true, 4); else RT_LAUNCH_EXTEND(false, true, false, false, 4); }
-    else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true, 5); else RT_LAUNCH_EXTEND(false, false, false, false, 5); }
+    else if (lds * 24 <= kLdsPerCu) {  // the walk on the 64-byte f32 records too (README scene forced onto them: 727 ms at five waves, 708 at six)
+      if (spill) RT_LAUNCH_EXTEND(false, false, false, true, 6); else RT_LAUNCH_EXTEND(false, false, false, false, 6);
+    } else { if (spill) RT_LAUNCH_EXTEND(false, false, false, true, 5); else RT_LAUNCH_EXTEND(false, false, false, false, 5); }
   }
 #undef RT_LAUNCH_EXTEND
 }

@@ -83,3 +83,25 @@ def test_blocks_of_stack_entries_really_move_and_change_nothing(monkeypatch, tmp
     differ = (p1[:k] != po) | (t1[:k] != to)
     assert differ.mean() < 0.02, differ.mean()
     assert np.all(p1[:k][differ] >= 0) and np.all((po[differ] < 0) | (t1[:k][differ] <= to[differ]))
+
+
+@pytest.mark.parametrize("spill_above", ["64", "16"])
+def test_walk_on_the_f32_node_records(monkeypatch, tmp_scene_dir, spill_above):
+    """Scenes whose boxes the 16-bit grid would inflate too much are walked on the 64-byte f32 records (RT_HIP_NO_GRID forces it):
+    same hits and image as on the grid records and as the oracle's, with the whole stack in LDS and with the overflow stack."""
+    from raytracer_amd.integrator import ResidentScene
+    ri = knot_scene(tmp_scene_dir, 20000, 40, 40, 8, 2, 2)
+    o, d = random_rays(150_000, seed=43)
+    grid = ri.resident(0)
+    p0, t0 = grid.trace_rays(o, d)
+    out0, st0 = grid.render(ri.config.copy())
+    monkeypatch.setenv("RT_HIP_NO_GRID", "1")
+    monkeypatch.setenv("RT_HIP_SPILL_ABOVE", spill_above)
+    res = ResidentScene(ri.scene, 0)
+    p1, t1 = res.trace_rays(o, d)
+    out1, st1 = res.render(ri.config.copy())
+    res.close()
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1)
+    assert np.array_equal(out0["linear"], out1["linear"]) and st0.rays == st1.rays
+    po, to = oracle.trace_rays(ri.scene, o, d)
+    assert np.array_equal(p1, po) and np.array_equal(t1, to)
