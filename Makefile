@@ -23,6 +23,8 @@ $(LIBDIR)/librt_host.so: $(HOSTSRC) raytracer_amd/csrc/host/scene.hpp raytracer_
 	@mkdir -p $(LIBDIR)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread -ffp-contract=off -Wall -o $@ $(HOSTSRC) -L$(LIBDIR) -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
 
+# portable on purpose (no -march): this file travels to machines with other CPUs.  The benchmark's CPU-baseline leg
+# compiles the same source with -march=native on the machine it measures (oracle/oracle.py: native_build).
 oracle/_build/librt_oracle.so: oracle/rt_oracle.c include/rt_hip.h
 	@mkdir -p oracle/_build
 	$(CC) -O3 -std=gnu11 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -o $@ oracle/rt_oracle.c -lm -lpthread

@@ -129,7 +129,24 @@ def rust_crate_check():
         return {"cargo": cargo, "checked": False, "error": str(e)}
 
 
-def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
+def load_roofline_inputs(path, source_hash):
+    """The committed counter sums, if they were taken on THIS build of the kernels: (inputs, None) or (None, why not)."""
+    if not os.path.exists(path):
+        return None, f"{os.path.relpath(path, ROOT)} is missing"
+    with open(path) as fh:
+        inputs = json.load(fh)
+    have = inputs.get("source_hash")
+    if have != source_hash:
+        return None, (f"{os.path.relpath(path, ROOT)} was measured on another build of the kernels (source hash {have}, this tree "
+                      f"{source_hash}): run tools/profile_round.sh and tools/summarize_profiles.py again")
+    return inputs, None
+
+
+# the event-timed kernel time of this run may differ from the profiled one by this factor before the counters are refused
+PROFILE_TIME_TOLERANCE = 0.15
+
+
+def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful, extend_launches=None):
     """Roofline figures of the two dominant kernels from the committed counter sums (per ray of the profiled render)
     and this run's event times.  Formulas:
       VALU busy  = 4 * SQ_ACTIVE_INST_VALU / (N_SIMD * GRBM_GUI_ACTIVE / 8)        [SQ counts quad-cycles; GRBM sums 8 XCDs]
@@ -150,7 +167,19 @@ def counter_roofline(inputs, rays, extend_ms, shade_ms, lanes_useful):
         fabric = (c["FETCH_SIZE"] * ff + c["WRITE_SIZE"]) * 1024.0 * scale
         l2 = (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) * 128.0 * scale
         valu_busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8.0)
+        time_ratio = None
+        if name == "k_extend" and extend_launches and c.get("kernel_avg_launch_ms"):
+            # The busy share above is that of the profiled run.  The same instructions issued over THIS run's kernel time
+            # (another box of the pool can be 5 % slower) are busy in proportion; a larger gap means something else than
+            # the box changed, and the counters are refused.
+            time_ratio = c["kernel_avg_launch_ms"] / (ms / extend_launches)  # same workload, same launches per render
+            if abs(time_ratio - 1.0) > PROFILE_TIME_TOLERANCE:
+                out["refused"] = (f"k_extend took {ms / extend_launches:.3f} ms per launch here but {c['kernel_avg_launch_ms']:.3f} ms when "
+                                  f"the counters were taken (more than {PROFILE_TIME_TOLERANCE:.0%} apart)")
+                continue
+            valu_busy *= time_ratio
         out[name] = {
+            "profiled_over_this_run_kernel_time": time_ratio,
             "fabric_bytes": fabric, "fabric_GBs": fabric / t / 1e9, "hbm_frac": fabric / t / 1e9 / HBM_PEAK_GBS,
             "l2_GBs": l2 / t / 1e9, "l2_frac": l2 / t / 1e9 / L2_PEAK_GBS,
             "l2_hit_rate": c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0),
@@ -302,15 +331,18 @@ def main():
         ref_cfg.rng_mode = abi.RT_RNG_REF
         probe = ref_cfg.copy()
         probe.row_first, probe.row_stride = H // 2, H  # one row through the middle of the image
-        t_p = time.perf_counter()
-        _, st_probe = oracle.render(ri.scene, probe, 1)
-        # one row on one thread; `threads` rows run concurrently in the sample
-        per_row = max(time.perf_counter() - t_p, 1e-3)
-        rows_wanted = max(threads, int(args.cpu_seconds / per_row * threads))
-        stride = max(1, H // min(H, rows_wanted))
-        sample = ref_cfg.copy()
-        sample.row_first, sample.row_stride = stride // 2, stride
-        _, st_cpu = oracle.render(ri.scene, sample, threads)
+        # compiled on this machine for this machine (-O3 -march=native, still no contraction and no fast-math: same bits)
+        with oracle.native_build():
+            cpu_flags = oracle.flags()
+            t_p = time.perf_counter()
+            _, st_probe = oracle.render(ri.scene, probe, 1)
+            # one row on one thread; `threads` rows run concurrently in the sample
+            per_row = max(time.perf_counter() - t_p, 1e-3)
+            rows_wanted = max(threads, int(args.cpu_seconds / per_row * threads))
+            stride = max(1, H // min(H, rows_wanted))
+            sample = ref_cfg.copy()
+            sample.row_first, sample.row_stride = stride // 2, stride
+            _, st_cpu = oracle.render(ri.scene, sample, threads)
         cpu_rows = sample.n_rows()
         v_int = st_cpu.node_visits / max(st_cpu.rays, 1)
         v_leaf = st_cpu.leaf_tests / max(st_cpu.rays, 1)
@@ -319,6 +351,7 @@ def main():
             "unit": "Mrays/s",
             "cores": threads,
             "kind": "port",
+            "compiler_flags": cpu_flags,
             "host": hc,
             "single_core_value": st_probe.rays / max(st_probe.wall_ms, 1e-6) / 1e3,
             "sample": f"rows {sample.row_first}::{stride} of the same {W}x{H} workload ({cpu_rows} rows, "
@@ -336,10 +369,12 @@ def main():
         value = rays_all / elapsed / 1e6
         headline = (args.triangles, W, H, args.batch, args.max_batches, args.min_batches) == (100_000, 1200, 1200, 20, 100, 2)
         working_set = sc.n_nodes // 2 * 32 + sc.n_triangles * (80 + 32)  # grid nodes + triangle test and shade records
-        counters = None
-        if os.path.exists(ROOFLINE_INPUTS) and headline and not opt_flags:
-            with open(ROOFLINE_INPUTS) as fh:
-                counters = counter_roofline(json.load(fh), rays_traced, trace_ms, shade_ms, lanes_useful)
+        counters, counters_note = None, "no counter sums for this workload (profiles/roofline_inputs.json covers the headline configuration)"
+        if headline and not opt_flags:
+            inputs, counters_note = load_roofline_inputs(ROOFLINE_INPUTS, abi.kernel_source_hash())
+            if inputs:
+                counters = counter_roofline(inputs, rays_traced, trace_ms, shade_ms, lanes_useful, launches)
+                counters_note = counters.get("refused")
         ext = (counters or {}).get("k_extend")
         roofline = {
             "kernel": "k_extend",
@@ -354,6 +389,11 @@ def main():
             "algorithmic_bytes_per_launch": rays * bytes_per_ray / max(launches, 1),
             "algorithmic_GBs": (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0,
             "working_set_bytes": working_set,
+            # the memory roofline the byte model belongs to: only a scene whose records leave the caches is bound by it
+            "hbm_roofline": ({"algorithmic_GBs": (rays * bytes_per_ray) / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0, "frac": None,
+                              "reason": f"working set {working_set / 1e6:.1f} MB is served by L2 / Infinity Cache: the algorithmic bytes never reach HBM "
+                                        "(counter traffic is in hbm_frac)"} if working_set < (256 << 20) else None),
+            "kernel_source_hash": abi.kernel_source_hash(),
             "node_visits_per_ray": v_int, "leaf_tests_per_ray": v_leaf,
             "node_visits_per_ray_device": v_int_dev, "leaf_tests_per_ray_device": v_leaf_dev,
             "simd_lane_utilisation": {"node_steps": lanes_node, "leaf_tests": lanes_leaf, "all_steps": lanes_useful},
@@ -383,8 +423,7 @@ def main():
             # no counter sums for this workload: only the byte model, which is NOT a fraction of the HBM roof when the
             # working set is cache resident
             roofline.update({"bound": "hbm" if working_set >= (256 << 20) else "valu-issue", "achieved": None, "peak": None,
-                             "unit": None, "frac": None, "traffic": None,
-                             "note": "no counter sums for this workload (profiles/roofline_inputs.json covers the headline configuration)"})
+                             "unit": None, "frac": None, "traffic": None, "note": counters_note})
         if counters and "k_shade" in counters:
             s = counters["k_shade"]
             roofline["second_kernel"] = {"kernel": "k_shade", "bound": "hbm", "achieved": s["fabric_GBs"], "peak": HBM_PEAK_GBS,

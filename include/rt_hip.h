@@ -328,22 +328,45 @@ int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
  * *n_nodes is written.  Works for uploaded and device-built scenes. */
 int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t capacity, int32_t *n_nodes);
 
+/* Tuning aid; no counterpart in the reference.  A handle's launch and scheduling parameters are read from the
+ * environment once, when rt_hip_scene_upload / rt_hip_scene_build make the handle (RT_HIP_REFILL, RT_HIP_CLAIM, ...:
+ * the variable of parameter `x` is RT_HIP_X); no render or query reads the environment afterwards.  This call changes
+ * one of them on an existing handle, for sweeps and tests:
+ *   refill, node_min, leafq, claim, tail     closest-hit kernel: idle lanes before a refill, lanes with node work below
+ *                                            which queued leaf tests run, leaves queued per lane, rays per claim, shrinking
+ *                                            last claims
+ *   wide_waves, ovf_waves                    waves per SIMD of the walks on wide nodes / with the block-overflow stack
+ *   shade_blocks                             most workgroups of a shading launch
+ *   max_paths, max_group, first_group        paths in flight per round (0: by memory), most batches per round, jump
+ *                                            after a quiet first round
+ *   tile_hlog, verbose
+ * None of them changes a pixel, a hit or a count.  Parameters that shape the device copy of the scene (wide, tri_pad,
+ * spill_above, no_grid, node order) are fixed when the handle is made and are refused here, as are unknown names and
+ * values out of range (RT_ERR_BAD_ARG). */
+int rt_hip_scene_tune(RtSceneHandle *handle, const char *name, int64_t value);
+
 /* The queries of rt_hip_trace_rays for callers that cannot allocate device
- * memory (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  It has no counterpart in the reference.  The call makes
- * no hipMalloc / hipFree and uses no allocating library routine: the ray
- * queue, hit buffer and counters live in a fixed array inside the library's
- * code object (about 7.5 MiB per GPU, held until the process ends).
+ * memory (tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The call makes no hipMalloc / hipFree and uses no allocating
+ * library routine: the ray queue, hit buffer and counters live in a fixed
+ * array inside the library's code object (about 7.5 MiB per GPU, held until
+ * the process ends).
  *   - d_origins, d_directions (3*n doubles each), d_prim_id, d_t (n each) are
- *     DEVICE pointers on the handle's device; results are complete on return.
+ *     DEVICE pointers on the handle's device.
  *   - n <= RT_NOALLOC_MAX_RAYS, otherwise RT_ERR_UNSUPPORTED (split the batch).
+ *   - Stream contract: the call is SYNCHRONOUS and runs on a stream of the
+ *     library's own.  The inputs must be complete before the call -- work that
+ *     produces them on a stream of the caller's is not waited for: synchronise
+ *     that stream (or an event recorded on it) first -- and the results are
+ *     complete when it returns.  It takes a host lock and ends with a stream
+ *     synchronisation, so it cannot itself be recorded into a graph capture.
  *   - All calls on one GPU share that GPU's array, which keeps the previous
  *     call's contents (the library clears what must start at zero).  Within a
  *     process the library lets one call at a time through per GPU, so calls
  *     from two threads or on two handles wait for each other instead of
  *     racing; rt_hip_scene_upload / rt_hip_scene_build trace one ray through
- *     the same path at set-up, where whatever the runtime prepares at a
- *     kernel's first launch may allocate. */
+ *     the same path at set-up (under the same lock), where whatever the
+ *     runtime prepares at a kernel's first launch may allocate. */
 #define RT_NOALLOC_MAX_RAYS 131072
 int rt_hip_trace_rays_noalloc(RtSceneHandle *handle, int64_t n, const double *d_origins,
                               const double *d_directions, int32_t *d_prim_id, double *d_t);

@@ -16,11 +16,29 @@ _LIB = os.path.join(_HERE, "_build", "librt_oracle.so")
 _lib = None
 
 
-def build():
-    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
-    subprocess.check_call([
-        "gcc", "-O3", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-        "-o", _LIB, os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"])
+# -ffp-contract=off -fno-fast-math: the Rust reference never fuses a multiply-add and never reassociates.
+BASE_FLAGS = ["-O3", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+_flags = " ".join(BASE_FLAGS)  # what the library in use was built with
+
+
+def build(out=_LIB, extra_flags=()):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["gcc"] + BASE_FLAGS + list(extra_flags) + ["-o", out, os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"])
+
+
+def _load(path):
+    l = C.CDLL(path)
+    l.rt_oracle_render.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtConfig), C.POINTER(abi.RtImage),
+                                   C.POINTER(abi.RtStats), C.c_int]
+    l.rt_oracle_primary_hits.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtConfig), C.c_void_p, C.c_void_p]
+    l.rt_oracle_trace_rays.argtypes = [C.POINTER(abi.RtScene), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    l.rt_oracle_sobol_sample.restype = C.c_float
+    l.rt_oracle_sobol_sample.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    l.rt_oracle_filter_evaluate.restype = C.c_double
+    l.rt_oracle_filter_evaluate.argtypes = [C.c_double] * 5
+    l.rt_oracle_quad_pdf_value.restype = C.c_double
+    l.rt_oracle_sphere_pdf_value.restype = C.c_double
+    return l
 
 
 def lib():
@@ -28,19 +46,39 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB):
             build()
-        l = C.CDLL(_LIB)
-        l.rt_oracle_render.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtConfig), C.POINTER(abi.RtImage),
-                                       C.POINTER(abi.RtStats), C.c_int]
-        l.rt_oracle_primary_hits.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtConfig), C.c_void_p, C.c_void_p]
-        l.rt_oracle_trace_rays.argtypes = [C.POINTER(abi.RtScene), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        l.rt_oracle_sobol_sample.restype = C.c_float
-        l.rt_oracle_sobol_sample.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
-        l.rt_oracle_filter_evaluate.restype = C.c_double
-        l.rt_oracle_filter_evaluate.argtypes = [C.c_double] * 5
-        l.rt_oracle_quad_pdf_value.restype = C.c_double
-        l.rt_oracle_sphere_pdf_value.restype = C.c_double
-        _lib = l
+        _lib = _load(_LIB)
     return _lib
+
+
+def flags():
+    """The compiler flags of the library lib() returns."""
+    return "gcc " + _flags
+
+
+class native_build:
+    """Context manager: the oracle compiled ON THIS MACHINE with -march=native (the in-tree library is built portable,
+    because it travels to machines with other CPUs), for the benchmark's CPU-baseline leg.  Results are the same to the
+    bit -- nothing in the flags licenses another rounding -- which tests/test_golden.py checks.  If the compiler is
+    missing or fails, the in-tree library stays in use and flags() says so."""
+
+    def __enter__(self):
+        global _lib, _flags
+        import tempfile
+        self._saved = (_lib, _flags)
+        self._dir = tempfile.TemporaryDirectory(prefix="rt_oracle_native_")
+        path = os.path.join(self._dir.name, "librt_oracle_native.so")
+        try:
+            build(path, ["-march=native"])
+            _lib, _flags = _load(path), " ".join(BASE_FLAGS + ["-march=native"])
+        except (OSError, subprocess.CalledProcessError):
+            lib()
+        return self
+
+    def __exit__(self, *exc):
+        global _lib, _flags
+        _lib, _flags = self._saved
+        self._dir.cleanup()
+        return False
 
 
 def _d3(v):

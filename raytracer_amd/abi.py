@@ -162,7 +162,7 @@ class RtStats(C.Structure):
 HIP_SYMBOLS = [
     "rt_hip_last_error", "rt_hip_device_count", "rt_hip_scene_upload", "rt_hip_scene_free",
     "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays", "rt_hip_set_progress",
-    "rt_hip_trace_rays_noalloc", "rt_hip_scene_build", "rt_hip_scene_download_tree",
+    "rt_hip_trace_rays_noalloc", "rt_hip_scene_build", "rt_hip_scene_download_tree", "rt_hip_scene_tune",
 ]
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
@@ -201,6 +201,7 @@ def hip_lib():
         lib.rt_hip_scene_build.argtypes = [C.POINTER(RtScene), C.c_int, C.POINTER(C.c_void_p)]
         lib.rt_hip_scene_download_tree.argtypes = [C.c_void_p, C.POINTER(RtNode), C.c_int32, C.POINTER(C.c_int32)]
         lib.rt_hip_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_hip_scene_tune.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         _hip = lib
     return _hip
 
@@ -236,6 +237,19 @@ def host_lib():
         lib.rt_host_save_to_png.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         _host = lib
     return _host
+
+
+KERNEL_SOURCES = ("csrc/rt_hip.hip", "csrc/rt_device.h", "csrc/rt_build_device.h")
+
+
+def kernel_source_hash():
+    """SHA-256 (first 16 hex digits) over the sources librt_hip.so is compiled from: what a profile was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def check_hip(rc):

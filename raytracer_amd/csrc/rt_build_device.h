@@ -336,11 +336,15 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   g_error.clear();
   if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
   *out = nullptr;
-  const bool verbose = getenv("RT_HIP_VERBOSE") != nullptr;
+  const Tuning tuning = tuning_from_env();
+  const bool verbose = tuning.verbose != 0;
   auto lap_t0 = std::chrono::steady_clock::now();
   int rc = validate_primitives(s);
   if (rc != RT_OK) return rc;
   const int32_t n = s->n_elements;
+  // internal-node indices and leaf slots are 28-bit fields of a child ref (elements may name a primitive more than once, so the
+  // per-kind counts checked above do not bound n); k_karras' range arithmetic i +- 2 * n also stays inside an int below this
+  if ((uint32_t)(n - 1) > kRefIndexMask) return fail(RT_ERR_UNSUPPORTED, "more than 2^28 elements: node indices do not fit a child reference");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "no such device");
@@ -363,6 +367,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
     }
   } unwind{h};
   h->device = device;
+  h->tuning = tuning;
   h->n_elements = n;
   if (hipStreamCreate(&h->stream) != hipSuccess) return fail(RT_ERR_HIP, "hipStreamCreate failed");
   hipStream_t st = h->stream;
@@ -427,8 +432,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   DevQuad *o_quads;
   DevSphere *o_spheres;
   // triangle records beyond the caches one per 128-byte line, as in an upload
-  const char *pad_env = getenv("RT_HIP_TRI_PAD");
-  const bool padded = pad_env ? atoi(pad_env) != 0 : n_tri_el * sizeof(DevTriangle) > ((size_t)256 << 20);
+  const bool padded = tuning.tri_pad >= 0 ? tuning.tri_pad != 0 : n_tri_el * sizeof(DevTriangle) > ((size_t)256 << 20);
   const uint32_t tri_stride = padded ? 128u : (uint32_t)sizeof(DevTriangle);
   {
     char *bytes = nullptr;
@@ -502,7 +506,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   HIP_TRY(hipGetLastError());
   h->dev.nodes = o_nodes;
   // the grid form only where it inflates the boxes by less than a tenth (summed edge lengths), as for uploaded trees
-  const bool use_grid = o_nodes_q && !getenv("RT_HIP_NO_GRID") && sums[0] <= 1.10 * sums[1];
+  const bool use_grid = o_nodes_q && !tuning.no_grid && sums[0] <= 1.10 * sums[1];
   h->dev.nodes_q = use_grid ? o_nodes_q : nullptr;
   h->dev.nodes_d = nullptr;
   h->dev.nodes_w = nullptr;
@@ -512,7 +516,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   // Trees beyond the caches also get the wide records of an upload, made the same way: the binary grid records come back to
   // the host, collapse_to_wide opens them four at a time, the result goes up (10 M triangles: 0.3 GB down, 0.3 GB up and one
   // pass of one host thread over the nodes: most of the preparation then, and still a fraction of a host build's).
-  if (use_grid && wide_nodes_wanted((size_t)n_internal)) {
+  if (use_grid && wide_nodes_wanted(tuning, (size_t)n_internal)) {
     auto t_w0 = std::chrono::steady_clock::now();
     std::vector<DevNodeQ> host_q((size_t)n_internal);
     HIP_TRY(hipMemcpy(host_q.data(), o_nodes_q, host_q.size() * sizeof(DevNodeQ), hipMemcpyDeviceToHost));

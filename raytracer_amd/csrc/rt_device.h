@@ -605,6 +605,7 @@ RT_DEV void trav_begin(uint32_t root, Traversal &tv) {
 //      high the tree -- and sit in cold branches, so the step costs one compare more than mode 0 and the LDS footprint no longer
 //      depends on the tree.
 constexpr int kOvfLevels = RT_OVF_LEVELS, kOvfBlock = 8;
+static_assert(kOvfLevels == 2 * kOvfBlock, "stack_block_out slides exactly one block down: the LDS part must hold two blocks");
 struct StackRef {
   uint32_t *lds;     // this lane's slot of level 0; levels are 64 entries apart
   uint32_t *spill;   // mode 1: this lane's slot of the first spilled level; mode 2: the wave's first slot of the buffer

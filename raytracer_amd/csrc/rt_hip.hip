@@ -536,24 +536,78 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   }
 }
 
-static ExtendTuning extend_tuning() {
-  ExtendTuning t{40, 20, kMaxLeafQueue, (int)kClaim, 1, 0, 0};
-  if (const char *e = getenv("RT_HIP_TAIL")) t.tail = std::max(0, atoi(e));
-  if (const char *e = getenv("RT_HIP_REFILL")) t.refill = std::max(1, std::min(64, atoi(e)));
-  if (const char *e = getenv("RT_HIP_NODE_MIN")) t.node_min = std::max(1, std::min(65, atoi(e)));
-  if (const char *e = getenv("RT_HIP_LEAFQ")) t.leafq = std::max(1, std::min(kMaxLeafQueue, atoi(e)));
-  if (const char *e = getenv("RT_HIP_CLAIM")) t.claim = std::max(64, std::min(1 << 16, atoi(e)));
+// Tuning of a scene handle.  Read from the environment ONCE PER HANDLE, when rt_hip_scene_upload / rt_hip_scene_build make it
+// (the variable names are in the table below), changed afterwards with rt_hip_scene_tune; no render and no query reads the
+// environment, so what a handle does never depends on what ran before it in the process.
+struct Tuning {
+  ExtendTuning extend{40, 20, kMaxLeafQueue, (int)kClaim, 1, 0, 0};
+  int wide_waves = 5;    // waves per SIMD of the walk on wide nodes (100 000 triangles: 690 ms at five, 719 at six)
+  int ovf_waves = 6;     // waves per SIMD of the binary walk with the block-overflow stack
+  int shade_blocks = 256 * 64;  // most workgroups of a k_shade launch
+  long long max_paths = 0;      // paths in flight per round; 0: what the memory allows, at most 2^29
+  int max_group = 64;    // most batches traced per round
+  int first_group = 8;   // jump after a quiet first round
+  int tile_hlog = -1;    // log2 of the tile height in shard rows; -1: by the row stride
+  int spill_above = kSpillAboveDepth;  // tree height above which the binary walks keep only the newest kOvfLevels stack entries in LDS
+  int verbose = 0;
+  // layout of the device copy, used while the handle is made only
+  int wide = -1, tri_pad = -1;  // -1: by size; 0 / 1: forced off / on
+  int node_order = -1;          // -1: by size; 0: the reference's preorder; 1: line-sized blocks
+  int no_grid = 0, no_exact_boxes = 0;
+};
+struct TuningName {
+  const char *env, *name;
+  int Tuning::*field;
+  int lo, hi;
+  bool layout;
+};
+static const TuningName kTuningNames[] = {
+    {"RT_HIP_WIDE_WAVES", "wide_waves", &Tuning::wide_waves, 4, 6, false},
+    {"RT_HIP_OVF_WAVES", "ovf_waves", &Tuning::ovf_waves, 5, 6, false},
+    {"RT_HIP_SHADE_BLOCKS", "shade_blocks", &Tuning::shade_blocks, kRegions, 1 << 20, false},
+    {"RT_HIP_MAX_GROUP", "max_group", &Tuning::max_group, 1, 1 << 20, false},
+    {"RT_HIP_FIRST_GROUP", "first_group", &Tuning::first_group, 1, 1 << 20, false},
+    {"RT_HIP_TILE_HLOG", "tile_hlog", &Tuning::tile_hlog, 0, 2 * RT_TILE_LOG, false},
+    {"RT_HIP_VERBOSE", "verbose", &Tuning::verbose, 0, 1, false},
+    {"RT_HIP_SPILL_ABOVE", "spill_above", &Tuning::spill_above, kOvfLevels, kMaxStackDepth, true},
+    {"RT_HIP_WIDE", "wide", &Tuning::wide, 0, 1, true},
+    {"RT_HIP_TRI_PAD", "tri_pad", &Tuning::tri_pad, 0, 1, true},
+    {"RT_HIP_NO_GRID", "no_grid", &Tuning::no_grid, 0, 1, true},
+    {"RT_HIP_NO_EXACT_BOXES", "no_exact_boxes", &Tuning::no_exact_boxes, 0, 1, true},
+};
+struct ExtendTuningName {
+  const char *env, *name;
+  int ExtendTuning::*field;
+  int lo, hi;
+};
+static const ExtendTuningName kExtendTuningNames[] = {
+    {"RT_HIP_TAIL", "tail", &ExtendTuning::tail, 0, 1 << 16},
+    {"RT_HIP_REFILL", "refill", &ExtendTuning::refill, 1, 64},
+    {"RT_HIP_NODE_MIN", "node_min", &ExtendTuning::node_min, 1, 65},
+    {"RT_HIP_LEAFQ", "leafq", &ExtendTuning::leafq, 1, kMaxLeafQueue},
+    {"RT_HIP_CLAIM", "claim", &ExtendTuning::claim, 64, 1 << 16},
+};
+static int clamp_int(long long v, int lo, int hi) { return (int)std::max<long long>(lo, std::min<long long>(hi, v)); }
+static Tuning tuning_from_env() {
+  Tuning t;
+  for (const TuningName &n : kTuningNames)
+    if (const char *e = getenv(n.env)) t.*n.field = clamp_int(atoll(e), n.lo, n.hi);
+  for (const ExtendTuningName &n : kExtendTuningNames)
+    if (const char *e = getenv(n.env)) t.extend.*n.field = clamp_int(atoll(e), n.lo, n.hi);
+  if (const char *e = getenv("RT_HIP_MAX_PATHS")) t.max_paths = std::max(0ll, atoll(e));
+  if (const char *e = getenv("RT_HIP_NODE_ORDER")) t.node_order = !strcmp(e, "blocks") ? 1 : 0;
+  // switches that count as set when the variable merely exists
+  if (getenv("RT_HIP_VERBOSE")) t.verbose = 1;
+  if (getenv("RT_HIP_NO_GRID")) t.no_grid = 1;
+  if (getenv("RT_HIP_NO_EXACT_BOXES")) t.no_exact_boxes = 1;
+  t.shade_blocks = std::max((int)kRegions, t.shade_blocks / (int)kRegions * (int)kRegions);
   return t;
 }
 
 // The walk that follows the reference's rule keeps its whole stack in LDS.
 static bool extend_wide(const DevScene &sc, bool quirk) { return !quirk && sc.nodes_w != nullptr; }
 // The binary order-free walks move blocks of stack entries out of LDS (rt_device.h, StackRef) exactly when upload gave the scene a
-// buffer for them: trees higher than `spill_above_depth()`.
-static int spill_above_depth() {
-  const char *e = getenv("RT_HIP_SPILL_ABOVE");
-  return e ? std::max(kOvfLevels, atoi(e)) : kSpillAboveDepth;
-}
+// buffer for them: trees higher than Tuning::spill_above.
 static bool extend_spills(const DevScene &sc, bool quirk) {
   if (extend_wide(sc, quirk)) return sc.stack_depth_w > kWideLdsLevels;
   return !quirk && sc.stack_spill != nullptr;
@@ -576,10 +630,10 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 // Which walk a query takes: 0 the order-free one, 1 the reference's visit rule for every ray,
 // 2 both -- the order-free walk for the rays that stay clear of the out-of-box primitives and
 // the reference's rule for the others.
-static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int pass, bool shared_origin, int64_t n_upper, hipStream_t st,
-                               PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
-  static const ExtendTuning base = extend_tuning();
-  ExtendTuning tune = base;
+static void launch_extend_pass(const DevScene &sc, const Tuning &tuning, bool quirk, bool counted, int pass, bool shared_origin, int64_t n_upper,
+                               hipStream_t st, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work,
+                               unsigned long long *visit_counters) {
+  ExtendTuning tune = tuning.extend;
   tune.pass = pass;
   tune.shared_origin = shared_origin;
   // persistent waves: enough to fill 256 CUs x 32 wave slots, never more than one per claim,
@@ -594,7 +648,7 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
     if (counted) RT_LAUNCH_EXTEND(true, true, false, false, 4);
     else RT_LAUNCH_EXTEND(true, false, false, false, 5);  // 96 registers, none in scratch (README scene, every ray by this rule: 1933 ms at four waves, 1697 at five, 1718 at six with 60 bytes of scratch)
   } else if (sc.nodes_w) {
-    static const int wide_waves = getenv("RT_HIP_WIDE_WAVES") ? atoi(getenv("RT_HIP_WIDE_WAVES")) : 5;  // 100 000 triangles: 690 ms at five waves per SIMD, 719 at six
+    const int wide_waves = tuning.wide_waves;
 #define RT_LAUNCH_WIDE(C, S, W) hipLaunchKernelGGL((k_extend<false, C, true, S, W, true>), g, b, lds, st, sc, q, count_ptr, hits, work, tune, visit_counters)
     // (eight-wide, 128-byte records were measured too: 10 M-triangle soup 40.8 instead of 57.1 records per ray, but k_extend
     // 126 ms at five waves per SIMD, 140 at four, against 101 on the four-wide ones)
@@ -606,8 +660,7 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
   } else if (sc.nodes_q) {
     if (counted) { if (spill) RT_LAUNCH_EXTEND(false, true, true, true, 4); else RT_LAUNCH_EXTEND(false, true, true, false, 4); }
     else if (spill) {
-      static const int ovf_waves = getenv("RT_HIP_OVF_WAVES") ? atoi(getenv("RT_HIP_OVF_WAVES")) : 6;
-      if (ovf_waves >= 6) RT_LAUNCH_EXTEND(false, false, true, true, 6);
+      if (tuning.ovf_waves >= 6) RT_LAUNCH_EXTEND(false, false, true, true, 6);
       else RT_LAUNCH_EXTEND(false, false, true, true, 5);
     } else if (lds * 24 <= kLdsPerCu) RT_LAUNCH_EXTEND(false, false, true, false, 6);  // the production kernel on trees up to height 22
     else RT_LAUNCH_EXTEND(false, false, true, false, 5);
@@ -623,13 +676,14 @@ static void launch_extend_pass(const DevScene &sc, bool quirk, bool counted, int
 // `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
 // passes, zeroed by the caller; all kCounterStride words apart.
 // `shared_origin`: the queue holds the primary rays k_generate wrote for a camera without a lens (no origins stored).
-static void launch_extend(const DevScene &sc, int mode, bool counted, bool shared_origin, int64_t n_upper, hipStream_t st, PathQueue q,
-                          const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, uint32_t *work2, unsigned long long *visit_counters) {
+static void launch_extend(const DevScene &sc, const Tuning &tuning, int mode, bool counted, bool shared_origin, int64_t n_upper, hipStream_t st,
+                          PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, uint32_t *work2,
+                          unsigned long long *visit_counters) {
   if (mode == 2) {
-    launch_extend_pass(sc, false, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
-    launch_extend_pass(sc, true, counted, 2, shared_origin, n_upper, st, q, count_ptr, hits, work2, visit_counters);
+    launch_extend_pass(sc, tuning, false, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    launch_extend_pass(sc, tuning, true, counted, 2, shared_origin, n_upper, st, q, count_ptr, hits, work2, visit_counters);
   } else {
-    launch_extend_pass(sc, mode == 1, counted, 0, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    launch_extend_pass(sc, tuning, mode == 1, counted, 0, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
   }
 }
 
@@ -1327,6 +1381,7 @@ struct RtSceneHandle {
   int32_t n_internal = 0;           // internal nodes resident on the device
   bool device_built = false;        // the tree was built by rt_hip_scene_build
   void *noalloc_scratch = nullptr;  // this device's address of the file-scope scratch array (rt_hip_trace_rays_noalloc)
+  Tuning tuning;                    // read from the environment when the handle was made, then rt_hip_scene_tune
 };
 
 Scratch::Scratch(RtSceneHandle *handle) : h(handle) {
@@ -1440,7 +1495,7 @@ int check_config(const RtConfig *cfg) {
   return RT_OK;
 }
 
-RenderParams make_params(const RtConfig *cfg) {
+RenderParams make_params(const RtConfig *cfg, const Tuning &tuning) {
   RenderParams rp{};
   rp.width = cfg->img_width;
   rp.height = cfg->img_height;
@@ -1471,7 +1526,7 @@ RenderParams make_params(const RtConfig *cfg) {
       for (int s = cfg->row_stride; s > 1 && rp.tile_hlog > 0; s >>= 1) rp.tile_hlog--;
     }
   }
-  if (const char *env = getenv("RT_HIP_TILE_HLOG")) rp.tile_hlog = (uint32_t)std::min<int>(2 * (int)kTileLog, std::max(0, atoi(env)));
+  if (tuning.tile_hlog >= 0) rp.tile_hlog = (uint32_t)std::min<int>(2 * (int)kTileLog, tuning.tile_hlog);
   rp.tile_wlog = 2 * kTileLog - rp.tile_hlog;
   rp.tiles_x = ((uint32_t)cfg->img_width + (1u << rp.tile_wlog) - 1u) >> rp.tile_wlog;
   rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + (1u << rp.tile_hlog) - 1u) >> rp.tile_hlog);
@@ -1628,9 +1683,8 @@ static int validate_primitives(const RtScene *s) {
 // same bytes, and is no faster while the binary records stay in the caches (k_extend 633 -> 690 ms; 2 M triangles 1115 -> 1180 ms);
 // on a 10 M-triangle soup, whose 320 MB of node records do not, it is 6 % faster.  Hence: made for trees above 256 MB of binary
 // records, RT_HIP_WIDE=1 / 0 forces them on / off.
-static bool wide_nodes_wanted(size_t n_internal) {
-  const char *wide_env = getenv("RT_HIP_WIDE");
-  return wide_env ? atoi(wide_env) != 0 : n_internal * sizeof(DevNodeQ) > ((size_t)256 << 20);
+static bool wide_nodes_wanted(const Tuning &tuning, size_t n_internal) {
+  return tuning.wide >= 0 ? tuning.wide != 0 : n_internal * sizeof(DevNodeQ) > ((size_t)256 << 20);
 }
 // `nodes_q`: the binary grid records, internal children named by their index in it; `root`: the root's index.  Leaves `nodes_w`
 // empty when a lane's stack could need more entries on them than the walk provides for.
@@ -1790,7 +1844,7 @@ static int alloc_stack_spill(RtSceneHandle *h) {
   h->dev.stack_spill = nullptr;
   // binary walks: blocks of kOvfBlock entries leave LDS when a push finds kOvfLevels there, i.e. with 16 + 8 b entries on the stack
   // and b blocks outside, and the stack never holds more entries than the tree is high
-  int levels = h->dev.stack_depth > spill_above_depth() ? ((h->dev.stack_depth - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock : 0;
+  int levels = h->dev.stack_depth > h->tuning.spill_above ? ((h->dev.stack_depth - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock : 0;
   if (h->dev.nodes_w && h->dev.stack_depth_w > kWideLdsLevels)
     levels = std::max(levels, RT_WIDE_STACK_MODE == 1 ? h->dev.stack_depth_w - kWideLdsLevels : ((h->dev.stack_depth_w - kOvfLevels - 1) / kOvfBlock + 1) * kOvfBlock);
   if (levels <= 0) return RT_OK;
@@ -1804,7 +1858,8 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   g_error.clear();
   if (!s || !out) return fail(RT_ERR_BAD_ARG, "scene or out is NULL");
   *out = nullptr;
-  const bool verbose = getenv("RT_HIP_VERBOSE") != nullptr;
+  const Tuning tuning = tuning_from_env();
+  const bool verbose = tuning.verbose != 0;
   auto lap_t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     auto now = std::chrono::steady_clock::now();
@@ -2025,8 +2080,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   // block starts at a node and takes in, largest box first (the child a ray is likeliest to enter),
   // descendants until the line is full; what is left over starts the next blocks.
   {
-    const char *order_env = getenv("RT_HIP_NODE_ORDER");
-    bool blocks = order_env ? !strcmp(order_env, "blocks") : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)64 << 20);
+    bool blocks = tuning.node_order >= 0 ? tuning.node_order == 1 : (size_t)n_internal * sizeof(DevNodeQ) > ((size_t)64 << 20);
     if (blocks && single_position) {
       constexpr int kPerLine = 128 / (int)sizeof(DevNodeQ);
       struct Cand { int32_t node; float area; };
@@ -2099,7 +2153,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   });
   // ---- the reference's own f64 boxes, for trees whose result depends on exactly which boxes a ray hits
   std::vector<DevNodeD> nodes_d;
-  if (!boxes_bound_contents && !getenv("RT_HIP_NO_EXACT_BOXES")) {  // (the switch exists for the test that shows why they are needed)
+  if (!boxes_bound_contents && !tuning.no_exact_boxes) {  // (the switch exists for the test that shows why they are needed)
     nodes_d.resize((size_t)n_internal);
     parallel_for((size_t)s->n_nodes, [&](size_t begin, size_t end) {
       for (size_t i = begin; i < end; i++) {
@@ -2121,7 +2175,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   // than a typical box would make every box test pass.
   std::vector<DevNodeQ> nodes_q;
   double grid_min[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
-  if (fast_walk_exists && !getenv("RT_HIP_NO_GRID")) {
+  if (fast_walk_exists && !tuning.no_grid) {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool finite = true;
     for (int i = 0; i < s->n_nodes; i++) {
@@ -2189,7 +2243,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   // ---- wide nodes (collapse_to_wide above)
   std::vector<DevNodeW> nodes_w;
   int32_t stack_depth_w = 1;
-  if (!nodes_q.empty() && !s->nodes[0].is_leaf && wide_nodes_wanted((size_t)n_internal)) {
+  if (!nodes_q.empty() && !s->nodes[0].is_leaf && wide_nodes_wanted(tuning, (size_t)n_internal)) {
     collapse_to_wide(nodes_q, (uint32_t)internal_index[0], grid_step, nodes_w, stack_depth_w);
     if (verbose) fprintf(stderr, "rt_hip upload: %zu wide nodes for %d binary ones, stack need %d\n", nodes_w.size(), n_internal, stack_depth_w);
   }
@@ -2265,6 +2319,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
     }
   } unwind{h};
   h->device = device;
+  h->tuning = tuning;
   h->n_elements = s->n_elements;
   h->bvh_depth = max_depth;
   h->n_internal = n_internal;
@@ -2284,8 +2339,7 @@ static int scene_upload_impl(const RtScene *s, int device, RtSceneHandle **out) 
   for (int a = 0; a < 3; a++) h->dev.grid_min[a] = grid_min[a], h->dev.grid_step[a] = grid_step[a];
   // Triangle records that do not fit the caches are fetched line by line from HBM: at 80 bytes apart every second
   // record lies across two 128-byte lines, at 128 bytes apart none does.
-  const char *pad_env = getenv("RT_HIP_TRI_PAD");
-  const bool padded = pad_env ? atoi(pad_env) != 0 : tris.size() * sizeof(DevTriangle) > ((size_t)256 << 20);
+  const bool padded = tuning.tri_pad >= 0 ? tuning.tri_pad != 0 : tris.size() * sizeof(DevTriangle) > ((size_t)256 << 20);
   h->dev.tri_stride = padded ? 128u : (uint32_t)sizeof(DevTriangle);
   if (padded) {
     struct alignas(128) Padded {
@@ -2339,7 +2393,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   if (out->memory != RT_MEM_HOST && out->memory != RT_MEM_DEVICE) return fail(RT_ERR_BAD_ARG, "bad RtImage.memory");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  RenderParams rp = make_params(cfg);
+  RenderParams rp = make_params(cfg, h->tuning);
   const int S = rp.S;
   const int32_t n_pix = rp.n_pix;
   const bool timed = (rp.flags & kFlagTimeKernels) != 0;
@@ -2359,12 +2413,8 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) max_paths = std::min<int64_t>(max_paths, (int64_t)((free_b + held) / 2) / bytes_per_path);
   }
   if (cfg->work_mib > 0) max_paths = std::min<int64_t>(max_paths, ((int64_t)cfg->work_mib << 20) / bytes_per_path);
-  if (const char *env = getenv("RT_HIP_MAX_PATHS")) {
-    long long v = atoll(env);
-    if (v >= 1) max_paths = v;
-  }
-  int max_group = 64;
-  if (const char *env = getenv("RT_HIP_MAX_GROUP")) max_group = std::max(1, atoi(env));
+  if (h->tuning.max_paths >= 1) max_paths = h->tuning.max_paths;
+  const int max_group = h->tuning.max_group;
   max_paths = std::max<int64_t>(max_paths, S);
   max_paths = std::min<int64_t>(max_paths, 0xfffffff0ll / 3);
   const int64_t cap_paths = std::min<int64_t>(max_paths / S * S, (int64_t)n_pix * S * std::min(rp.max_batches, max_group));
@@ -2481,8 +2531,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   int b = 0;
   int group = 1;
   // after the first round: jump straight to this many batches if (almost) no pixel stopped in it
-  int first_jump = 8;
-  if (const char *env = getenv("RT_HIP_FIRST_GROUP")) first_jump = std::max(1, atoi(env));
+  const int first_jump = h->tuning.first_group;
   while (b < rp.max_batches && n_active > 0) {
     // how many batches this round traces at once
     int G;
@@ -2502,7 +2551,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       HIP_TRY(hipMemsetAsync(qcounts, 0, (n_counters - kCounterStride) * sizeof(uint32_t), st));
       // k_shade: a whole number of workgroups per region, and many more of them than fit the
       // chip at once -- short workgroups even out the uneven cost of the material branches
-      static const int shade_blocks = getenv("RT_HIP_SHADE_BLOCKS") ? std::max((int)kRegions, atoi(getenv("RT_HIP_SHADE_BLOCKS")) / (int)kRegions * (int)kRegions) : 256 * 64;
+      const int shade_blocks = h->tuning.shade_blocks;
       int g_shade = (int)std::min<int64_t>(shade_blocks, (np / kShadeBlock / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
       if (S <= kGenMaxShared) {
@@ -2515,7 +2564,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
         HIP_TRY(mark_begin(0, k));
-        launch_extend(h->dev, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
+        launch_extend(h->dev, h->tuning, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
                       totals + RT_MAX_DEPTH_STATS + 1);
         LAUNCHED("k_extend");
         HIP_TRY(mark_end());
@@ -2595,7 +2644,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     stats->wave_cycles_node = host_totals[RT_MAX_DEPTH_STATS + 7];
     stats->wave_cycles_leaf = host_totals[RT_MAX_DEPTH_STATS + 8];
     stats->stack_block_moves = host_totals[RT_MAX_DEPTH_STATS + 12];
-    if (getenv("RT_HIP_VERBOSE") && host_totals[RT_MAX_DEPTH_STATS + 4]) {
+    if (h->tuning.verbose && host_totals[RT_MAX_DEPTH_STATS + 4]) {
       // sampled at the first of the 1 + RT_EXTRA_STEPS node steps between two votes (the reference-rule walk votes after every step)
       const double sampled_slots = 64.0 * host_totals[RT_MAX_DEPTH_STATS + 4] / (walk == 1 ? 1.0 : 1.0 + RT_EXTRA_STEPS);
       fprintf(stderr, "[rt_hip] lanes of a node step that are not visiting a node: no ray %.3f, walk over but leaf tests pending %.3f, holding a leaf %.3f\n",
@@ -2618,7 +2667,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         stats->other_kernel_ms += ms;
       }
     }
-    if (getenv("RT_HIP_VERBOSE") && timed) {
+    if (h->tuning.verbose && timed) {
       fprintf(stderr, "[rt_hip] k_shade ms by bounce:");
       for (int k = 0; k < rp.max_depth && k < RT_MAX_DEPTH_STATS; k++) fprintf(stderr, " %.1f", shade_ms_by_depth[k]);
       fprintf(stderr, "\n");
@@ -2636,6 +2685,34 @@ int rt_hip_set_progress(RtSceneHandle *h, RtProgressFn fn, void *user) {
   return RT_OK;
 }
 
+static int scene_tune_impl(RtSceneHandle *h, const char *name, int64_t value) {
+  g_error.clear();
+  if (!h || !name) return fail(RT_ERR_BAD_ARG, "handle or name is NULL");
+  auto out_of_range = [&](long long lo, long long hi) {
+    return fail(RT_ERR_BAD_ARG, std::string(name) + " must lie in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+  };
+  if (!strcmp(name, "max_paths")) {
+    if (value < 0) return out_of_range(0, INT64_MAX);
+    h->tuning.max_paths = value;
+    return RT_OK;
+  }
+  for (const TuningName &n : kTuningNames)
+    if (!strcmp(name, n.name)) {
+      if (n.layout) return fail(RT_ERR_BAD_ARG, std::string(name) + " shapes the device copy of the scene: set " + n.env + " before the handle is made");
+      if (value < n.lo || value > n.hi) return out_of_range(n.lo, n.hi);
+      h->tuning.*n.field = (int)value;
+      if (n.field == &Tuning::shade_blocks) h->tuning.shade_blocks = std::max((int)kRegions, (int)value / (int)kRegions * (int)kRegions);
+      return RT_OK;
+    }
+  for (const ExtendTuningName &n : kExtendTuningNames)
+    if (!strcmp(name, n.name)) {
+      if (value < n.lo || value > n.hi) return out_of_range(n.lo, n.hi);
+      h->tuning.extend.*n.field = (int)value;
+      return RT_OK;
+    }
+  return fail(RT_ERR_BAD_ARG, std::string("no tuning parameter named ") + name);
+}
+
 static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, uint32_t *d_counts, int32_t flags, int32_t *prim_id, double *t) {
   const size_t entries = (size_t)q.cap * kRegions;
   HitBuffer hits;
@@ -2647,7 +2724,7 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   HIP_TRY(sc.alloc(&d_t, (size_t)n));
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
-  launch_extend(h->dev, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  launch_extend(h->dev, h->tuning, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
   LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
   LAUNCHED("k_hits_to_elements");
@@ -2678,7 +2755,7 @@ static int primary_hits_impl(RtSceneHandle *h, const RtConfig *cfg, int32_t *pri
   int rc = check_config(cfg);
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(h->device));
-  RenderParams rp = make_params(cfg);
+  RenderParams rp = make_params(cfg, h->tuning);
   int64_t n = (int64_t)rp.n_pix * rp.S;
   Scratch sc(h);
   PathQueue q;
@@ -2746,17 +2823,9 @@ static int noalloc_scratch_of(int device, void **out) {
   return RT_OK;
 }
 
-static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_origins, const double *d_directions, int32_t *d_prim_id,
-                                   double *d_t) {
-  g_error.clear();
-  if (!h || n < 0 || (n > 0 && (!d_origins || !d_directions || !d_prim_id || !d_t))) return fail(RT_ERR_BAD_ARG, "NULL argument or negative count");
-  if (n > kNoAllocMaxRays)
-    return fail(RT_ERR_UNSUPPORTED, "rt_hip_trace_rays_noalloc takes at most " + std::to_string(kNoAllocMaxRays) + " rays per call, got " +
-                                        std::to_string(n) + ": split the batch or use rt_hip_trace_rays");
-  if (n == 0) return RT_OK;
-  if (!h->noalloc_scratch) return fail(RT_ERR_HIP, "the scene handle has no scratch address");
-  HIP_TRY(hipSetDevice(h->device));
-  std::lock_guard<std::mutex> one_at_a_time(g_noalloc_busy[h->device]);
+// The query itself; the caller holds g_noalloc_busy[h->device] and has made h->device current.
+static int trace_rays_noalloc_locked(RtSceneHandle *h, int64_t n, const double *d_origins, const double *d_directions, int32_t *d_prim_id,
+                                     double *d_t) {
   // carve the device's copy of the array: counters first, then the queue and the hit buffer
   unsigned char *base = static_cast<unsigned char *>(h->noalloc_scratch);
   uint32_t *d_counts = reinterpret_cast<uint32_t *>(base);
@@ -2774,7 +2843,7 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   hipLaunchKernelGGL(k_caller_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, n, d_origins, d_directions, q, d_counts);
   LAUNCHED("k_caller_rays");
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
-  launch_extend(h->dev, walk_mode(h, 0), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  launch_extend(h->dev, h->tuning, walk_mode(h, 0), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
   LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, n, q.cap, hits, d_prim_id, d_t);
   LAUNCHED("k_hits_to_elements");
@@ -2783,17 +2852,34 @@ static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_
   return RT_OK;
 }
 
+static int trace_rays_noalloc_impl(RtSceneHandle *h, int64_t n, const double *d_origins, const double *d_directions, int32_t *d_prim_id,
+                                   double *d_t) {
+  g_error.clear();
+  if (!h || n < 0 || (n > 0 && (!d_origins || !d_directions || !d_prim_id || !d_t))) return fail(RT_ERR_BAD_ARG, "NULL argument or negative count");
+  if (n > kNoAllocMaxRays)
+    return fail(RT_ERR_UNSUPPORTED, "rt_hip_trace_rays_noalloc takes at most " + std::to_string(kNoAllocMaxRays) + " rays per call, got " +
+                                        std::to_string(n) + ": split the batch or use rt_hip_trace_rays");
+  if (n == 0) return RT_OK;
+  if (!h->noalloc_scratch) return fail(RT_ERR_HIP, "the scene handle has no scratch address");
+  HIP_TRY(hipSetDevice(h->device));
+  std::lock_guard<std::mutex> one_at_a_time(g_noalloc_busy[h->device]);
+  return trace_rays_noalloc_locked(h, n, d_origins, d_directions, d_prim_id, d_t);
+}
+
 // Set-up for rt_hip_trace_rays_noalloc: trace one ray through it now.  Whatever the runtime sets up lazily at a kernel's first
 // launch on a queue (loading the code object, private-segment memory for the few registers the walk keeps there) happens
 // here, where allocating is allowed, and not inside a caller's first query.  The ray and its result live in the last 256 bytes
-// of the scratch array, which a one-ray query does not use otherwise.
+// of the scratch array, which a one-ray query does not use otherwise -- but a full-size query of another thread does (they are
+// the last hit references of its last region), so the device's lock is held from the copy of the ray to the end of the query:
+// a set-up never writes into a query in flight on the same GPU.
 static int noalloc_warm_up(RtSceneHandle *h) {
   static_assert(kNoAllocBytes > kNoAllocCounterBytes + 64 * kRegions * 60 + 256, "room for the warm-up ray behind a one-ray queue");
   unsigned char *tail = static_cast<unsigned char *>(h->noalloc_scratch) + kNoAllocBytes - 256;
   const double ray[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+  std::lock_guard<std::mutex> one_at_a_time(g_noalloc_busy[h->device]);
   HIP_TRY(hipMemcpy(tail, ray, sizeof ray, hipMemcpyHostToDevice));
   double *d = reinterpret_cast<double *>(tail);
-  return trace_rays_noalloc_impl(h, 1, d, d + 3, reinterpret_cast<int32_t *>(d + 7), d + 6);
+  return trace_rays_noalloc_locked(h, 1, d, d + 3, reinterpret_cast<int32_t *>(d + 7), d + 6);
 }
 
 #include "rt_build_device.h"
@@ -2804,6 +2890,9 @@ int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out) {
 }
 int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t capacity, int32_t *n_nodes) {
   return guarded([&] { return scene_download_tree_impl(handle, nodes, capacity, n_nodes); });
+}
+int rt_hip_scene_tune(RtSceneHandle *handle, const char *name, int64_t value) {
+  return guarded([&] { return scene_tune_impl(handle, name, value); });
 }
 int rt_hip_scene_upload(const RtScene *scene, int device, RtSceneHandle **out) {
   return guarded([&] { return scene_upload_impl(scene, device, out); });

@@ -31,6 +31,12 @@ class ResidentScene:
         abi.check_hip(abi.hip_lib().rt_hip_scene_download_tree(self._h, nodes, n.value, C.byref(n)))
         return nodes
 
+    def tune(self, **params):
+        """Set launch / scheduling parameters of this handle (rt_hip_scene_tune): res.tune(max_group=5, first_group=3)."""
+        for name, value in params.items():
+            abi.check_hip(abi.hip_lib().rt_hip_scene_tune(self._h, name.encode(), int(value)))
+        return self
+
     def close(self):
         if self._h:
             abi.hip_lib().rt_hip_scene_free(self._h)

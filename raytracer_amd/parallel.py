@@ -37,6 +37,9 @@ def max_rows(height, world, row_block=ROW_BLOCK):
     return max(len(shard_rows(height, r, world, row_block)) for r in range(world))
 
 
+_buffers = {}  # persistent staging of gather_rows: one set per (shape, dtype, device, sharding)
+
+
 def gather_rows(local, height, rank, world, dst=0, row_block=ROW_BLOCK, row_dim=0):
     """Gather per-rank shards into the full image on `dst` with ONE collective.
 
@@ -44,28 +47,47 @@ def gather_rows(local, height, rank, world, dst=0, row_block=ROW_BLOCK, row_dim=
     rank's rows (shard_rows order); other leading dimensions may stack several planes (image and
     heat-map) so that they travel together.  Ranks may own different row counts; shards are padded
     to the largest for the collective.  Returns the assembled tensor on `dst`, None elsewhere.
+
+    A contiguous shard with the largest row count is sent as it is.  Whatever the call needs beyond
+    that -- the padded send buffer of a shorter shard (its pad rows zeroed once), the receive buffers,
+    the row indices -- is allocated at the first call for a shape and reused by the later ones; only the
+    assembled tensor is new every time (uninitialised memory from torch's allocator, every row then written
+    once), because the caller keeps it.
     """
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return local
-    rows_first = local.movedim(row_dim, 0)
     mr = max_rows(height, world, row_block)
-    if rows_first.shape[0] < mr or not rows_first.is_contiguous():
-        pad = torch.zeros((mr,) + tuple(rows_first.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: rows_first.shape[0]] = rows_first
-    else:
-        pad = rows_first
+    rows_here = local.shape[row_dim]
+    key = (tuple(local.shape), row_dim, local.dtype, str(local.device), height, rank, world, dst, row_block)
+    buf = _buffers.get(key)
+    if buf is None:
+        shape = list(local.shape)
+        shape[row_dim] = mr
+        buf = {}
+        if rows_here < mr or not local.is_contiguous():
+            buf["send"] = torch.empty(shape, dtype=local.dtype, device=local.device)
+            buf["send"].narrow(row_dim, rows_here, mr - rows_here).zero_()
+        if rank == dst:
+            buf["parts"] = [torch.empty(shape, dtype=local.dtype, device=local.device) for _ in range(world)]
+            buf["rows"] = [torch.as_tensor(shard_rows(height, r, world, row_block), device=local.device) for r in range(world)]
+        _buffers[key] = buf
+    send = local
+    if "send" in buf:
+        send = buf["send"]
+        send.narrow(row_dim, 0, rows_here).copy_(local)
     if rank == dst:
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.gather(pad, gather_list=parts, dst=dst)
-        full = torch.empty((height,) + tuple(pad.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.gather(send, gather_list=buf["parts"], dst=dst)
+        shape = list(local.shape)
+        shape[row_dim] = height
+        full = torch.empty(shape, dtype=local.dtype, device=local.device)
         for r in range(world):
-            rows = shard_rows(height, r, world, row_block)
-            full[torch.as_tensor(rows, device=local.device)] = parts[r][: len(rows)]
-        return full.movedim(0, row_dim)
-    dist.gather(pad, gather_list=None, dst=dst)
+            rows = buf["rows"][r]
+            full.index_copy_(row_dim, rows, buf["parts"][r].narrow(row_dim, 0, len(rows)))
+        return full
+    dist.gather(send, gather_list=None, dst=dst)
     return None
 
 

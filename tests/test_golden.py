@@ -64,6 +64,24 @@ def test_oracle_sampler_golden():
     assert oracle.rng_stream(abi.RT_RNG_REF, 42, 1, 16) == list(g["gen_range_seed42"])
 
 
+def test_native_build_of_the_oracle_matches_the_goldens(tmp_scene_dir):
+    """The benchmark's CPU baseline runs the oracle compiled with -march=native on the machine it measures; the flags
+    license no other rounding (no contraction, no fast-math), so every golden vector must come out the same."""
+    with oracle.native_build():
+        assert "-march=native" in oracle.flags(), "this machine has gcc: the native build must succeed here"
+        test_oracle_primary_hits_golden()
+        test_oracle_render_golden()
+        test_oracle_adaptive_golden(tmp_scene_dir)
+        test_oracle_sampler_golden()
+        g = _load("c1_render_24x24x16.npz")
+        ri = c1(width=24, height=24, batch=16)
+        ctr, _ = oracle.render(ri.scene, ri.config.copy(), 3)
+    base, _ = oracle.render(ri.scene, ri.config.copy(), 3)
+    assert "-march=native" not in oracle.flags()
+    for k in base:  # and bit for bit the in-tree build's image (libm is the same library either way)
+        assert np.array_equal(base[k], ctr[k]), k
+
+
 @pytest.mark.gpu
 def test_gpu_primary_hits_golden():
     g = _load("c1_primary_32x32x4.npz")

@@ -431,12 +431,11 @@ def test_counters_and_timers():
     assert st.node_visits >= 0.999 * so.node_visits and st.node_visits <= 1.02 * so.node_visits
 
 
-def test_chunked_rounds_give_the_same_image(monkeypatch):
+def test_chunked_rounds_give_the_same_image():
     ri = c1(width=32, height=32, batch=8, max_batches=3, min_batches=0)
     cfg = ri.config.copy()
     a, _ = ri.resident(0).render(cfg)
-    monkeypatch.setenv("RT_HIP_MAX_PATHS", "1000")
-    b, _ = ri.resident(0).render(cfg)
+    b, _ = ri.resident(0).tune(max_paths=1000).render(cfg)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
 
@@ -474,17 +473,15 @@ def test_render_devices_interleaves_to_the_single_device_image(tmp_scene_dir):
         ri.render_devices([0, 99])
 
 
-def test_round_size_does_not_change_the_image(monkeypatch, tmp_scene_dir):
+def test_round_size_does_not_change_the_image(tmp_scene_dir):
     """Batches are traced in rounds of several at once, speculatively past a pixel's stopping batch; however the
     rounds are cut, every pixel must end with the batches the reference's sequential loop would have used."""
     ri = knot_scene(tmp_scene_dir, 2000, 40, 40, 32, 40, 1)
     cfg = ri.config.copy()
     res = ri.resident(0)
     outs = []
-    for group, first in (("1", "1"), ("5", "3"), ("64", "8"), ("64", "64")):
-        monkeypatch.setenv("RT_HIP_MAX_GROUP", group)
-        monkeypatch.setenv("RT_HIP_FIRST_GROUP", first)
-        out, st = res.render(cfg)
+    for group, first in ((1, 1), (5, 3), (64, 8), (64, 64)):
+        out, st = res.tune(max_group=group, first_group=first).render(cfg)
         outs.append((out, int(st.rays), int(st.samples), int(st.batches)))
     assert len({o[3] for o in outs}) > 1  # the rounds really differed
     stopped_early = (outs[0][0]["samples"] < 32 * 40).mean()

@@ -28,6 +28,10 @@ stacked = torch.stack([local, -local])
 both = parallel.gather_rows(stacked, H, rank, world, row_block=B, row_dim=1)
 if rank == 0:
     assert torch.equal(both[0], full) and torch.equal(both[1], -full)
+# a second gather of the same shape reuses the staging buffers of the first but must not write into its result
+again = parallel.gather_rows(local * 2.0, H, rank, world, row_block=B)
+if rank == 0:
+    assert torch.equal(again, full * 2.0) and torch.equal(both[0], full)
 counts = torch.tensor([float(len(rows))], dtype=torch.float64)
 dist.all_reduce(counts)
 if rank == 0:

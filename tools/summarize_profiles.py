@@ -20,6 +20,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import abi  # noqa: E402
 
 
 def short_name(kernel):
@@ -85,7 +87,8 @@ def main():
             if ms:
                 fam["kernel_avg_launch_ms"] = sum(m["total_ms"] for m in ms) / max(sum(m["calls"] for m in ms), 1)
             kernels[name] = fam
-    inputs = {"tag": tag, "rays": rays_traced, "rays_accepted": rays, "fetch_factor": fetch_factor, "kernels": kernels,
+    # the counters belong to the kernels as they were when the passes ran: run this tool on the tree the passes were taken on
+    inputs = {"tag": tag, "source_hash": abi.kernel_source_hash(), "source_hash_of": list(abi.KERNEL_SOURCES), "rays": rays_traced, "rays_accepted": rays, "fetch_factor": fetch_factor, "kernels": kernels,
               "workload": bench["config"]["workload"],
               "note": "counter sums of ONE render (bench.py --profile-pass), one rocprofv3 --pmc pass per counter group; "
                       "FETCH_SIZE / WRITE_SIZE in KiB; SQ_* cycle counters in quad-cycles; GRBM_GUI_ACTIVE summed over 8 XCDs"}
