@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--profile-pass", action="store_true",
                     help="exactly one render and nothing else on the GPU (for rocprofv3 counter passes): implies --steps 1 --warmup 0, "
                          "no CPU baseline, no instrumented render")
+    ap.add_argument("--no-reuse-leg", action="store_true", help="skip the extra renders with RT_FLAG_REUSE_PRIMARY_HITS")
     ap.add_argument("--dry-run", action="store_true", help="print the launch plan (child command and environment) and exit")
     args = ap.parse_args(argv)
     if args.profile_pass:
@@ -258,7 +259,7 @@ def main():
         host_planes = torch.empty(2, H, W, 3, dtype=torch.float64, pin_memory=True)
 
     def step():
-        _, st = res.render(cfg, device_out=out)
+        _, st = res.render(cfg, device_out=out)  # (`cfg` is looked up at call time: the reuse leg below swaps it)
         full = parallel.gather_rows(planes, H, rank, world, row_block=row_block, row_dim=1)
         if rank == 0:
             host_planes.copy_(full, non_blocking=True)  # final f64 image + heat-map on the rank-0 host
@@ -305,6 +306,35 @@ def main():
     else:
         trace_ms_max = trace_ms
     rays_all, launches_all, samples_all = float(tot[1]), float(tot[3]), float(tot[4])
+
+    # ---- beside the headline: the same image with RT_FLAG_REUSE_PRIMARY_HITS (every primary ray traced once per round
+    # instead of once per batch: identical pixels, fewer queries executed than the reference makes).  Timed like the
+    # headline steps but never part of `value`.
+    reuse = None
+    if not args.profile_pass and not args.no_reuse_leg:
+        cfg_reuse = cfg.copy()
+        cfg_reuse.flags = cfg.flags | abi.RT_FLAG_REUSE_PRIMARY_HITS
+        saved, cfg = cfg, cfg_reuse
+        n_reuse = max(1, min(args.steps, 3))
+        step()
+        sync()
+        t_r0 = time.perf_counter()
+        for _ in range(n_reuse):
+            st_r = step()
+        sync()
+        t_reuse = (time.perf_counter() - t_r0) / n_reuse
+        cfg = saved
+        tr = torch.tensor([t_reuse, float(st_r.rays), float(st_r.rays_traced)], dtype=torch.float64, device=dev)
+        if world > 1:
+            mxr = tr.clone()
+            dist.all_reduce(mxr, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+            t_reuse = float(mxr[0])
+        reuse = {"flag": "RT_FLAG_REUSE_PRIMARY_HITS", "steps": n_reuse, "time_to_image_s": t_reuse,
+                 "rays_reference_equivalent_per_step": float(tr[1]), "rays_executed_per_step": float(tr[2]),
+                 "mrays_executed_per_s": float(tr[2]) / t_reuse / 1e6,
+                 "extend_ms": st_r.trace_kernel_ms, "shade_ms": st_r.shade_kernel_ms, "other_ms": st_r.other_kernel_ms,
+                 "note": "same pixels and sample counts as the headline render (tests/test_gpu_reuse.py); not part of `value`"}
 
     # ---- untimed instrumented render: device-side visit counts for the byte model and the lane utilisation
     cfg_cnt = cfg.copy()
@@ -462,6 +492,9 @@ def main():
             "time_to_image_with_load_build_upload_s": elapsed / args.steps + t_host + t_upload,
             "time_to_image_with_load_build_upload_in_a_fresh_process_s": elapsed / args.steps + t_host + t_upload_first,
             "roofline": roofline,
+            "reuse_primary_hits": reuse,
+            "time_to_image_reuse_s": reuse["time_to_image_s"] if reuse else None,
+            "mrays_executed": reuse["mrays_executed_per_s"] if reuse else None,
             "cpu_baseline": cpu,
             "rust_sys_crate": rust_crate_check(),
         }

@@ -80,6 +80,21 @@ extern "C" {
  *                         them).  This flag forces the reference's rule for
  *                         every ray (same pixels, more node visits). */
 #define RT_FLAG_REFERENCE_VISIT_RULE 8
+/* RT_FLAG_REUSE_PRIMARY_HITS  The reference restarts the Sobol index with every
+ *                         batch (integrator.rs:284-289), so without a lens
+ *                         (camera_defocus_angle <= 0, camera.rs:104-105) sample i
+ *                         of a pixel sends the SAME primary ray into the scene
+ *                         in every batch, and the reference traces it again
+ *                         each time.  With this flag the device traces each
+ *                         such ray once per round of batches and lets the
+ *                         batches share its hit; what follows the first hit
+ *                         (random streams per batch) is unchanged.  Pixels,
+ *                         sample counts and RtStats.rays (the queries the
+ *                         reference makes) are identical to a render without
+ *                         the flag; RtStats.rays_traced and rays_by_depth[0]
+ *                         report the queries really executed, which are fewer.
+ *                         Ignored for a camera with a lens. */
+#define RT_FLAG_REUSE_PRIMARY_HITS 16
 
 /* RtImage.memory */
 #define RT_MEM_HOST 0

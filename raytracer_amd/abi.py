@@ -21,6 +21,7 @@ RT_PRIM_SPHERE, RT_PRIM_QUAD, RT_PRIM_TRIANGLE = 0, 1, 2
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RT_RNG_REF, RT_RNG_CTR = 0, 1
 RT_FLAG_TIME_KERNELS, RT_FLAG_COUNT_VISITS, RT_FLAG_EARLY_TERMINATE, RT_FLAG_REFERENCE_VISIT_RULE = 1, 2, 4, 8
+RT_FLAG_REUSE_PRIMARY_HITS = 16
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
 RT_MAX_DEPTH_STATS = 16
 RT_NOALLOC_MAX_RAYS = 131072

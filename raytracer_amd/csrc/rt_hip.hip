@@ -74,6 +74,7 @@ constexpr int32_t kFlagTimeKernels = RT_FLAG_TIME_KERNELS;
 constexpr int32_t kFlagCountVisits = RT_FLAG_COUNT_VISITS;
 constexpr int32_t kFlagEarlyTerminate = RT_FLAG_EARLY_TERMINATE;
 constexpr int32_t kFlagReferenceVisitRule = RT_FLAG_REFERENCE_VISIT_RULE;
+constexpr int32_t kFlagReusePrimaryHits = RT_FLAG_REUSE_PRIMARY_HITS;
 
 // ==================================================================== queues
 // SoA path state.  One "queue" holds the rays about to be traced at a bounce.
@@ -200,17 +201,31 @@ RT_DEV GenSample generate_sample(const DevScene &sc, const RenderParams &rp, con
   gs.pixel_key = rng_seed_pixel((uint64_t)y * (uint64_t)rp.width + (uint64_t)x);
   return gs;
 }
-RT_DEV void generate_store(const DevScene &sc, const RenderParams &rp, const GenSample &gs, uint32_t batch, uint32_t i, uint32_t j, uint32_t e, const PathQueue &q) {
+// Primary rays traced once per round (RT_FLAG_REUSE_PRIMARY_HITS, cameras without a lens): the G batches of a round send the SAME
+// S rays through a pixel, so the rays go into a compact queue of their own -- one entry per (pixel slot, sample), entry
+// slot * S + i dealt over the regions like any queue -- and every path only remembers which compact entry is its ray.
+struct PrimaryReuse {
+  double *dx, *dy, *dz;  // the compact queue's directions (origins: the camera centre)
+  uint32_t *entry;       // per path (indexed like the path queue): its ray's entry in the compact queue
+  uint32_t *counts;      // the compact queue's entries per region
+  uint32_t cap;          // its entries per region; 0: no reuse, every path carries its own ray
+};
+RT_DEV void generate_store(const DevScene &sc, const RenderParams &rp, const GenSample &gs, uint32_t batch, uint32_t i, uint32_t j, uint32_t e, const PathQueue &q,
+                           const PrimaryReuse &pr, uint32_t entry) {
   uint64_t rng = rng_seed_path_of(gs.pixel_key, (uint64_t)batch, (uint64_t)i, rp.seed);
-  d3 dir = gs.dir;
-  // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
-  if (!(sc.camera.defocus_angle <= 0.0)) {
-    d3 pd = random_in_unit_disk(rng);
-    d3 origin = ld3(sc.camera.camera_center) + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
-    dir = normalized(gs.pixel_sample - origin);
-    q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+  if (pr.cap) {
+    pr.entry[e] = entry;
+  } else {
+    d3 dir = gs.dir;
+    // without a lens every primary ray starts at the camera centre: the first bounce's kernels know
+    if (!(sc.camera.defocus_angle <= 0.0)) {
+      d3 pd = random_in_unit_disk(rng);
+      d3 origin = ld3(sc.camera.camera_center) + (ld3(sc.camera.defocus_disk_u) * pd.x) + (ld3(sc.camera.defocus_disk_v) * pd.y);
+      dir = normalized(gs.pixel_sample - origin);
+      q.ox[e] = origin.x; q.oy[e] = origin.y; q.oz[e] = origin.z;
+    }
+    q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
   }
-  q.dx[e] = dir.x; q.dy[e] = dir.y; q.dz[e] = dir.z;
   // throughput starts at one: bounce 0 of k_shade knows, nothing is stored
   q.rng[e] = rng;
   q.pid[e] = j;
@@ -220,13 +235,19 @@ RT_DEV void generate_store(const DevScene &sc, const RenderParams &rp, const Gen
 // in the queue, in order: whole lines per store instruction.
 constexpr int kGenMaxShared = 512;  // (slot, sample) pairs per workgroup; S above it takes k_generate_strided
 __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots, int32_t spb,
-                                                   int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
+                                                   int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts, PrimaryReuse pr) {
   __shared__ double sh_f64[3][kGenMaxShared];
   __shared__ uint64_t sh_key[kGenMaxShared];
+  __shared__ uint32_t sh_entry[kGenMaxShared];
   // n fits 32 bits (the host caps a round below 2^32 / 3 paths): 32-bit arithmetic throughout
   const int64_t n = (int64_t)n_slots * G * rp.S;
   const uint32_t share = region_share(n);
-  if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
+  const int64_t n_rays = (int64_t)n_slots * rp.S;  // entries of the compact queue
+  const uint32_t share_rays = region_share(n_rays);
+  if (blockIdx.x == 0) {
+    region_publish_counts(n, share, qcounts);
+    if (pr.cap) region_publish_counts(n_rays, share_rays, pr.counts);
+  }
   const uint32_t S = (uint32_t)rp.S, GS = (uint32_t)G * S;
   const bool lens = !(sc.camera.defocus_angle <= 0.0);
   const uint32_t n_chunks = ((uint32_t)n_slots + (uint32_t)spb - 1u) / (uint32_t)spb;
@@ -239,6 +260,11 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
       const d3 v = lens ? gs.pixel_sample : gs.dir;
       sh_f64[0][k] = v.x; sh_f64[1][k] = v.y; sh_f64[2][k] = v.z;
       sh_key[k] = gs.pixel_key;
+      if (pr.cap) {  // this lane's (slot, sample) is one ray of the compact queue
+        const uint32_t entry = region_place((int64_t)slot0 * S + k, share_rays, pr.cap);
+        sh_entry[k] = entry;
+        pr.dx[entry] = v.x; pr.dy[entry] = v.y; pr.dz[entry] = v.z;
+      }
     }
     __syncthreads();
     const uint32_t j0 = slot0 * GS, count = slots * GS;
@@ -254,27 +280,37 @@ __global__ void __launch_bounds__(256) k_generate(DevScene sc, RenderParams rp, 
       GenSample gs;
       gs.pixel_sample = gs.dir = D3(sh_f64[0][k], sh_f64[1][k], sh_f64[2][k]);
       gs.pixel_key = sh_key[k];
-      generate_store(sc, rp, gs, (uint32_t)batch0 + g, i, j, e, q);
+      generate_store(sc, rp, gs, (uint32_t)batch0 + g, i, j, e, q, pr, pr.cap ? sh_entry[k] : 0u);
     }
   }
 }
 // The same for batches of more than kGenMaxShared samples: one lane takes (active pixel slot, sample i), does the shared
 // arithmetic once and writes the G paths of the round's batches (runs of S entries, G * S apart).
 __global__ void __launch_bounds__(256) k_generate_strided(DevScene sc, RenderParams rp, const uint32_t *active, int32_t n_slots,
-                                                           int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts) {
+                                                           int32_t batch0, int32_t G, PathQueue q, double *weights, uint32_t *qcounts, PrimaryReuse pr) {
   const int64_t n = (int64_t)n_slots * G * rp.S;
   const uint32_t share = region_share(n);
-  if (blockIdx.x == 0) region_publish_counts(n, share, qcounts);
+  const int64_t n_rays = (int64_t)n_slots * rp.S;
+  const uint32_t share_rays = region_share(n_rays);
+  if (blockIdx.x == 0) {
+    region_publish_counts(n, share, qcounts);
+    if (pr.cap) region_publish_counts(n_rays, share_rays, pr.counts);
+  }
   const uint32_t lb = xcd_logical_block(blockIdx.x, gridDim.x);
   const uint32_t S = (uint32_t)rp.S, n_si = (uint32_t)n_slots * S;
   for (uint32_t k = lb * blockDim.x + threadIdx.x; k < n_si; k += gridDim.x * blockDim.x) {
     const uint32_t slot = k / S, i = k - slot * S;
     const GenSample gs = generate_sample(sc, rp, active, slot, i, batch0, weights);
+    uint32_t entry = 0;
+    if (pr.cap) {
+      entry = region_place((int64_t)k, share_rays, pr.cap);
+      pr.dx[entry] = gs.dir.x; pr.dy[entry] = gs.dir.y; pr.dz[entry] = gs.dir.z;
+    }
     // entry of the path of batch g: j = (slot * G + g) * S + i, region by region (region_place)
     uint32_t j = slot * (uint32_t)G * S + i;
     uint32_t r = j / share, off = j - r * share;
     for (int32_t g = 0; g < G; g++) {
-      generate_store(sc, rp, gs, (uint32_t)(batch0 + g), i, j, r * q.cap + off, q);
+      generate_store(sc, rp, gs, (uint32_t)(batch0 + g), i, j, r * q.cap + off, q, pr, entry);
       j += S;
       off += S;
       while (off >= share) {
@@ -781,9 +817,13 @@ constexpr int kShadeCategories = 4;
 #define RT_SHADE_BLOCK 256
 #endif
 constexpr int kShadeBlock = RT_SHADE_BLOCK, kShadeWaves = kShadeBlock / 64;  // paths a workgroup sorts together
+// REUSE (bounce 0 of a round whose primary rays were traced once, PrimaryReuse above): a path's ray and hit are those of the
+// compact queue's entry pr.entry[j]; `hits` is that queue's hit buffer.
+template <bool REUSE>
 __attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q, const uint32_t *count_ptr, HitBuffer hits, PathQueue out,
-                                                       uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags) {
+                                                       uint32_t *out_count, PathResults res, int32_t bounce, int32_t last_bounce, int32_t flags,
+                                                       PrimaryReuse pr) {
   constexpr int kLdsMaterials = 64;
   __shared__ DevMaterial lds_materials[kLdsMaterials];
   __shared__ double lds_f64[13][kShadeBlock];  // point, normal, throughput, direction (3 each), material parameter
@@ -806,11 +846,11 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q,
   const uint32_t in0 = region * q.cap, out0 = region * out.cap;
   uint32_t *out_counter = out_count + region * kCounterStride;
   const uint32_t jj0 = (blockIdx.x / kRegions) * (uint32_t)kShadeBlock + threadIdx.x;
-  uint32_t ref_ahead = jj0 < n ? hits.ref[in0 + jj0] : kRefNone;
+  uint32_t ref_ahead = (!REUSE && jj0 < n) ? hits.ref[in0 + jj0] : kRefNone;
   for (uint32_t jj = jj0; jj - threadIdx.x < n_round; jj += stride) {
     const uint32_t j = in0 + jj;
     const uint32_t ref_now = ref_ahead;
-    ref_ahead = (jj + stride < n) ? hits.ref[j + stride] : kRefNone;
+    if (!REUSE) ref_ahead = (jj + stride < n) ? hits.ref[j + stride] : kRefNone;
     // ---- phase A: load, classify, decide whether the path goes on
     int cat = -1;  // 0 Lambertian by cosine, 1 Lambertian towards an attractor, 2 Metal, 3 Dielectric
     {
@@ -821,13 +861,14 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q,
       uint64_t rng = 0;
       uint32_t pid = 0;
       if (jj < n) {
-        uint32_t ref = ref_now;
-        double t = hits.t[j];
+        const uint32_t hj = REUSE ? pr.entry[j] : j;  // where the path's ray and hit are
+        uint32_t ref = REUSE ? hits.ref[hj] : ref_now;
+        double t = hits.t[hj];
         pid = q.pid[j];
         rng = q.rng[j];
         T = bounce ? D3(q.tx[j], q.ty[j], q.tz[j]) : D3(1.0, 1.0, 1.0);
-        d3 o = (bounce == 0 && sc.camera.defocus_angle <= 0.0) ? ld3(sc.camera.camera_center) : D3(q.ox[j], q.oy[j], q.oz[j]);
-        d = D3(q.dx[j], q.dy[j], q.dz[j]);
+        d3 o = (REUSE || (bounce == 0 && sc.camera.defocus_angle <= 0.0)) ? ld3(sc.camera.camera_center) : D3(q.ox[j], q.oy[j], q.oz[j]);
+        d = REUSE ? D3(pr.dx[hj], pr.dy[hj], pr.dz[hj]) : D3(q.dx[j], q.dy[j], q.dz[j]);
         bool dead_weight = (flags & kFlagEarlyTerminate) && T.x == 0.0 && T.y == 0.0 && T.z == 0.0;
         if (ref != kRefNone && !dead_weight) {
           point = o + d * t;  // Ray::at
@@ -1040,11 +1081,13 @@ constexpr int kAccChunk = 4;  // batches k_accumulate evaluates together
 __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint32_t *active, int32_t n_slots, int32_t batch0, int32_t G,
                                                      PathResults res, const double *weights, double *sums, double *hist,
                                                      uint32_t *next_active, uint32_t *next_count, PixelOutputs out, const uint32_t *qcounts,
-                                                     unsigned long long *totals) {
+                                                     const uint32_t *qcounts_primary, unsigned long long *totals) {
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // queue sizes = queries traced per bounce (first wave)
     for (int k = 0; k < rp.max_depth; k++) {
       unsigned long long c = 0;
-      for (int r = threadIdx.x; r < kRegions; r += 64) c += qcounts[((size_t)k * kRegions + r) * kCounterStride];
+      // (the primary rays of a round that traces them once per pixel and sample have a queue of their own)
+      const uint32_t *qc = (k == 0 && qcounts_primary) ? qcounts_primary : qcounts + (size_t)k * kRegions * kCounterStride;
+      for (int r = threadIdx.x; r < kRegions; r += 64) c += qc[(size_t)r * kCounterStride];
       for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
       if (threadIdx.x == 0) totals[1 + (k < RT_MAX_DEPTH_STATS ? k : RT_MAX_DEPTH_STATS - 1)] += c;
     }
@@ -2429,11 +2472,17 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   PathResults results;
   double *weights, *sums, *hist = nullptr;
   uint32_t *active[2], *counters;
+  // Primary rays once per round (RT_FLAG_REUSE_PRIMARY_HITS): possible when no lens moves the origin from batch to batch
+  const bool reuse_primary = (rp.flags & kFlagReusePrimaryHits) && h->dev.camera.defocus_angle <= 0.0 && rp.max_depth > 0;
+  PrimaryReuse primary{};
+  HitBuffer primary_hits{};
+  const uint32_t primary_cap = (uint32_t)((((int64_t)n_pix * S + kRegions - 1) / kRegions + 63) / 64 * 64);
   // counters (each on its own 128-byte line): [0] next_count; then per bounce 0..max_depth the
   // kRegions queue sizes; then per bounce the kRegions work-claim counters of k_extend, twice
   // (a tree with stray primitives is walked in two launches per bounce, each claiming the whole queue)
   const size_t per_bounce = (size_t)kRegions * kCounterStride;
-  const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1) * per_bounce;
+  // ... and last the compact queue of primary rays traced once per round: its sizes and its two sets of claim counters
+  const size_t n_counters = kCounterStride + (size_t)(3 * rp.max_depth + 1 + 3) * per_bounce;
   // totals: [0] BVH queries of accepted samples, [1..16] queries traced per bounce, [17] node visits,
   // [18] leaf tests, [19] accepted samples, [20] wave node steps, [21] wave leaf steps
   constexpr int kTotals = RT_MAX_DEPTH_STATS + 13;  // ... [22..24] wave cycles in refill / node steps / leaf tests and retire, [25..27] lane states, [28] stack block moves
@@ -2460,6 +2509,13 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
     }
     HIP_TRY(sc.alloc(&hits.t, q_entries));
     HIP_TRY(sc.alloc(&hits.ref, q_entries));
+    if (reuse_primary) {
+      const size_t pe = (size_t)primary_cap * kRegions;
+      HIP_TRY(sc.alloc(&primary.dx, pe)); HIP_TRY(sc.alloc(&primary.dy, pe)); HIP_TRY(sc.alloc(&primary.dz, pe));
+      HIP_TRY(sc.alloc(&primary.entry, q_entries));
+      HIP_TRY(sc.alloc(&primary_hits.t, pe));
+      HIP_TRY(sc.alloc(&primary_hits.ref, pe));
+    }
     HIP_TRY(sc.alloc(&results.rec, cap_paths));
     HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)n_pix));
     HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
@@ -2496,6 +2552,8 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
   uint32_t *qcounts = counters + kCounterStride;
   uint32_t *work = qcounts + (size_t)(rp.max_depth + 1) * per_bounce;
   uint32_t *work2 = work + (size_t)rp.max_depth * per_bounce;
+  uint32_t *primary_counts = work2 + (size_t)rp.max_depth * per_bounce, *primary_work = primary_counts + per_bounce, *primary_work2 = primary_work + per_bounce;
+  primary.counts = primary_counts;
   const int walk = walk_mode(h, rp.flags);
   HIP_TRY(hipMemsetAsync(totals, 0, kTotals * sizeof(unsigned long long), st));
 
@@ -2554,23 +2612,38 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       const int shade_blocks = h->tuning.shade_blocks;
       int g_shade = (int)std::min<int64_t>(shade_blocks, (np / kShadeBlock / kRegions + 1) * kRegions);
       HIP_TRY(mark_begin(2));
+      // one batch per round has nothing to share: its paths carry their rays as usual
+      PrimaryReuse pr = primary;
+      pr.cap = (reuse_primary && G > 1) ? primary_cap : 0u;
+      PathQueue primary_q{};
+      primary_q.dx = pr.dx; primary_q.dy = pr.dy; primary_q.dz = pr.dz;
+      primary_q.cap = primary_cap;
       if (S <= kGenMaxShared) {
         const int spb = std::max(1, std::min(block, kGenMaxShared) / S);  // pixel slots per workgroup: about one (slot, sample) per lane
-        hipLaunchKernelGGL(k_generate, dim3(grid_for(((int64_t)ns + spb - 1) / spb, 1, 1 << 20)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, spb, b, G, q[0], weights, qcounts);
+        hipLaunchKernelGGL(k_generate, dim3(grid_for(((int64_t)ns + spb - 1) / spb, 1, 1 << 20)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, spb, b, G, q[0], weights, qcounts, pr);
       } else {
-        hipLaunchKernelGGL(k_generate_strided, dim3(grid_for((int64_t)ns * S, block, max_blocks)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts);
+        hipLaunchKernelGGL(k_generate_strided, dim3(grid_for((int64_t)ns * S, block, max_blocks)), dim3(block), 0, st, h->dev, rp, active[cur] + base, ns, b, G, q[0], weights, qcounts, pr);
       }
       LAUNCHED("k_generate");
       HIP_TRY(mark_end());
       for (int k = 0; k < rp.max_depth; k++) {
+        const bool shared_rays = k == 0 && pr.cap != 0;  // this bounce's rays are the compact queue's
         HIP_TRY(mark_begin(0, k));
-        launch_extend(h->dev, h->tuning, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce, work2 + k * per_bounce,
-                      totals + RT_MAX_DEPTH_STATS + 1);
+        if (shared_rays)
+          launch_extend(h->dev, h->tuning, walk, counted, true, (int64_t)ns * S, st, primary_q, primary_counts, primary_hits, primary_work, primary_work2,
+                        totals + RT_MAX_DEPTH_STATS + 1);
+        else
+          launch_extend(h->dev, h->tuning, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce,
+                        work2 + k * per_bounce, totals + RT_MAX_DEPTH_STATS + 1);
         LAUNCHED("k_extend");
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1, k));
-        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(kShadeBlock), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1], qcounts + (k + 1) * per_bounce,
-                           results, k, (int32_t)(k == rp.max_depth - 1), rp.flags);
+        if (shared_rays)
+          hipLaunchKernelGGL(k_shade<true>, dim3(g_shade), dim3(kShadeBlock), 0, st, h->dev, q[0], qcounts, primary_hits, q[1], qcounts + per_bounce, results, 0,
+                             (int32_t)(rp.max_depth == 1), rp.flags, pr);
+        else
+          hipLaunchKernelGGL(k_shade<false>, dim3(g_shade), dim3(kShadeBlock), 0, st, h->dev, q[k & 1], qcounts + k * per_bounce, hits, q[(k + 1) & 1],
+                             qcounts + (k + 1) * per_bounce, results, k, (int32_t)(k == rp.max_depth - 1), rp.flags, pr);
         LAUNCHED("k_shade");
         HIP_TRY(mark_end());
       }
@@ -2579,7 +2652,7 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         HIP_TRY(hipMemsetAsync(results.rec, 0, (size_t)np * sizeof(PathRecord), st));
       }
       hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ns, block, max_blocks)), dim3(block), 0, st, rp, active[cur] + base, ns, b, G, results, weights,
-                         sums, hist, active[cur ^ 1], counters, po, qcounts, totals);
+                         sums, hist, active[cur ^ 1], counters, po, qcounts, pr.cap ? primary_counts : nullptr, totals);
       LAUNCHED("k_accumulate");
       HIP_TRY(mark_end());
     }
