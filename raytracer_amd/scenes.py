@@ -196,12 +196,39 @@ def knot_mesh(n_triangles=100_000, seed=7):
     return verts, faces
 
 
-def write_obj(path, verts, faces):
-    """Plain `v` / `f` Wavefront file, 1-based indices, like input/obj/teapot.obj."""
+def _write_obj_part(args):
+    path, kind, rows = args
     with open(path, "w") as f:
-        f.write("# generated by raytracer_amd.scenes.knot_mesh\n")
-        np.savetxt(f, verts, fmt="v %.6f %.6f %.6f")
-        np.savetxt(f, faces + 1, fmt="f %d %d %d")
+        np.savetxt(f, rows, fmt="v %.6f %.6f %.6f" if kind == "v" else "f %d %d %d")
+    return path
+
+
+def write_obj(path, verts, faces, workers=None):
+    """Plain `v` / `f` Wavefront file, 1-based indices, like input/obj/teapot.obj.  Files of millions of lines are
+    formatted by several processes (pieces written side by side, then joined): formatting text is all the time there is."""
+    lines = len(verts) + len(faces)
+    if workers is None:
+        workers = 1 if lines < 2_000_000 else max(1, min(8, len(os.sched_getaffinity(0))))
+    if workers <= 1:
+        with open(path, "w") as f:
+            f.write("# generated by raytracer_amd.scenes.knot_mesh\n")
+            np.savetxt(f, verts, fmt="v %.6f %.6f %.6f")
+            np.savetxt(f, faces + 1, fmt="f %d %d %d")
+        return
+    import shutil
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = []
+    for kind, rows in (("v", verts), ("f", faces + 1)):
+        for k, piece in enumerate(np.array_split(rows, 2 * workers)):
+            jobs.append((f"{path}.part_{kind}{k:03d}", kind, piece))
+    with ProcessPoolExecutor(max_workers=workers) as pool:
+        parts = list(pool.map(_write_obj_part, jobs))
+    with open(path, "wb") as out:
+        out.write(b"# generated by raytracer_amd.scenes\n")
+        for part in parts:
+            with open(part, "rb") as f:
+                shutil.copyfileobj(f, out, 1 << 24)
+            os.remove(part)
 
 
 def scene_c3(obj_path, defocus_angle=0.0):
