@@ -115,3 +115,68 @@ def test_noalloc_calls_from_two_threads_on_two_scenes_wait_for_each_other(tmp_sc
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_noalloc_inputs_made_on_another_stream_must_be_finished_first(tmp_scene_dir):
+    """The call runs on a stream of the library's own and waits for nobody else's work: inputs produced on a caller's
+    (non-blocking) stream are synchronised by the caller first, as the header says; then the results are those of
+    rt_hip_trace_rays."""
+    torch = pytest.importorskip("torch")
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    res = ri.resident(0)
+    o, d = random_rays(90_000, seed=61)
+    want_id, want_t = res.trace_rays(o, d)
+    side = torch.cuda.Stream()  # non-blocking with respect to the legacy default stream
+    pinned_o, pinned_d = torch.from_numpy(np.ascontiguousarray(o)).pin_memory(), torch.from_numpy(np.ascontiguousarray(d)).pin_memory()
+    d_id = torch.full((o.shape[0],), -7, dtype=torch.int32, device="cuda")
+    d_t = torch.full((o.shape[0],), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        d_o = pinned_o.to("cuda", non_blocking=True)
+        d_d = (pinned_d.to("cuda", non_blocking=True) * 3.0) / 3.0 * 1.0  # a kernel on the side stream too
+        d_d = pinned_d.to("cuda", non_blocking=True)
+    side.synchronize()  # the contract: inputs complete before the call
+    res.trace_rays_noalloc(d_o, d_d, d_id, d_t)
+    # results are complete on return: read them on yet another stream without further synchronisation
+    with torch.cuda.stream(torch.cuda.Stream()):
+        got_id, got_t = d_id.cpu().numpy(), d_t.cpu().numpy()
+    assert np.array_equal(got_id, want_id) and np.array_equal(got_t, want_t)
+
+
+def test_noalloc_queries_are_not_disturbed_by_scene_set_up_on_the_same_gpu(tmp_scene_dir):
+    """Scene set-up traces one ray through the same array (its ray sits in the array's last bytes, which a full-size
+    query uses for hit references): it takes the GPU's lock like any query, so uploads overlapping full-size queries
+    leave every result intact."""
+    import threading
+    torch = pytest.importorskip("torch")
+    from raytracer_amd.integrator import ResidentScene
+    ri = knot_scene(tmp_scene_dir, 20000, 16, 16, 1, 1, 1)
+    small = c1(width=8, height=8, batch=1)
+    res = ri.resident(0)
+    o, d = random_rays(abi.RT_NOALLOC_MAX_RAYS, seed=71)
+    want_id, want_t = res.trace_rays(o, d)
+    buf = (torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda(),
+           torch.empty(o.shape[0], dtype=torch.int32, device="cuda"), torch.empty(o.shape[0], dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+    errors, stop = [], threading.Event()
+
+    def uploads():
+        try:
+            while not stop.is_set():
+                ResidentScene(small.scene, 0).close()
+                ResidentScene(small.scene, 0, build_on_device=True).close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=uploads)
+    t.start()
+    try:
+        for _ in range(25):
+            res.trace_rays_noalloc(*buf)
+            if not (np.array_equal(buf[2].cpu().numpy(), want_id) and np.array_equal(buf[3].cpu().numpy(), want_t)):
+                errors.append("a query returned other hits while a scene was being set up")
+                break
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
