@@ -354,6 +354,8 @@ int rt_hip_scene_download_tree(RtSceneHandle *handle, RtNode *nodes, int32_t cap
  *   shade_blocks                             most workgroups of a shading launch
  *   max_paths, max_group, first_group        paths in flight per round (0: by memory), most batches per round, jump
  *                                            after a quiet first round
+ *   packet                                   1 / 0: bounce 0 by the packet walk (64 neighbouring primary rays walk the
+ *                                            tree together) or by the general one
  *   tile_hlog, verbose
  * None of them changes a pixel, a hit or a count.  Parameters that shape the device copy of the scene (wide, tri_pad,
  * spill_above, no_grid, node order) are fixed when the handle is made and are refused here, as are unknown names and

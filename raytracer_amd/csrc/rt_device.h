@@ -542,6 +542,46 @@ RT_DEV bool slab_hit_q(float qminx, float qminy, float qminz, float qmaxx, float
   return tn <= fminf(tf, tmax);
 }
 
+// Ray constants for the f32 boxes in the form one fma per plane: the slab distance of plane b on an axis is
+// (b - o) / d = b * I + C with I = 1/d and C = -o * I.  I carries a relative error (conversion of d, the reciprocal
+// instruction), but the SAME I multiplies b and o, so that error is relative to the distance itself and the factor on the
+// far side in slab_hit_p absorbs it, as in slab_hit_f32; the product b * I is exact inside the fma.  What is absolute is the
+// rounding of C (computed in f64, rounded once: 2^-24 |C|): E = 2^-22 |C| is folded into the constants, C - E for the plane
+// the ray meets first and C + E for the other (which of the two box planes that is depends on the sign of I only).  A
+// direction component of zero (or below 1e-25) counts as +-1e-25, as in rayq_axis and for the same reason.
+struct RayP {
+  float ix, iy, iz;
+  float clx, cly, clz;  // added to b_min * I
+  float chx, chy, chz;  // added to b_max * I
+};
+RT_DEV void rayp_axis(double o, double d, float &i_out, float &cl_out, float &ch_out) {
+  float inv = __builtin_amdgcn_rcpf((float)d);
+  inv = fminf(fmaxf(inv, -1e25f), 1e25f);
+  if (!(inv == inv)) inv = 1e25f;
+  const float c = (float)(-o * (double)inv);
+  const float e = fabsf(c) * 2.4e-7f + 1e-30f;
+  i_out = inv;
+  cl_out = inv >= 0.0f ? c - e : c + e;
+  ch_out = inv >= 0.0f ? c + e : c - e;
+}
+RT_DEV RayP make_rayp(d3 o, d3 d) {
+  RayP r;
+  rayp_axis(o.x, d.x, r.ix, r.clx, r.chx);
+  rayp_axis(o.y, d.y, r.iy, r.cly, r.chy);
+  rayp_axis(o.z, d.z, r.iz, r.clz, r.chz);
+  return r;
+}
+// Passes whenever the reference's f64 test on a box inside (bmin, bmax) does, and never rejects a box that begins at or before `tmax`.
+RT_DEV bool slab_hit_p(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayP &r, float tmax, float &tn_out) {
+  float tlx = fmaf(bminx, r.ix, r.clx), thx = fmaf(bmaxx, r.ix, r.chx);
+  float tly = fmaf(bminy, r.iy, r.cly), thy = fmaf(bmaxy, r.iy, r.chy);
+  float tlz = fmaf(bminz, r.iz, r.clz), thz = fmaf(bmaxz, r.iz, r.chz);
+  float tn = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), 0.0f));
+  float tf = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fmaxf(tlz, thz));
+  tn_out = tn;
+  return tn <= fminf(tf, tmax) * 1.000001f;
+}
+
 // Does the ray come near one of the out-of-box primitives?  Slab test in f64 on their true bounds
 // (padded at upload); passes whenever the ray could touch the box.
 RT_DEV bool hits_danger_box(const DevScene &sc, d3 o, d3 d) {

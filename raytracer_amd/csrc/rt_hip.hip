@@ -572,6 +572,143 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   }
 }
 
+// ------------------------------------------------------------- packet walk
+// The closest-hit queries of a queue whose neighbouring entries are NEARLY THE SAME RAY: primary rays (64 consecutive
+// entries are the samples of one or two pixels, each of them G times when the batches of a round repeat the ray).  The 64
+// rays of a wave walk the tree TOGETHER: one node at a time for the whole wave, its record fetched once through the scalar
+// unit, every lane testing its own ray against the two child boxes, the wave entering a child if any lane hits it (the child
+// more lanes meet first goes first, the other waits on ONE stack, kept in LDS with the set of lanes that hit it).  A leaf is
+// tested by the lanes that hit its box.  Per lane this is the order-free walk of k_extend on the 64-byte f32 records -- the
+// same conservative box test, the same primitive tests on the same candidates or fewer, ties by leaf rank -- so results are
+// those of k_extend; what changes is the price: no per-lane stack, no divergence between lanes that are at different nodes,
+// one record fetch per node instead of sixty-four.  For rays that do not travel together it would be ruinous (the wave
+// visits the union of what its lanes need): the host uses it for bounce 0 only.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+RT_DEV u32x16 scalar_load_node(const DevNode *nodes, uint32_t index) {  // `index` is the same in every lane
+  const uint64_t address = reinterpret_cast<uint64_t>(nodes) + (uint64_t)__builtin_amdgcn_readfirstlane(index) * sizeof(DevNode);
+  u32x16 v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(address) : "memory");
+  return v;
+}
+constexpr int kPacketStack = kMaxStackDepth + 2;
+template <bool COUNT, int WAVES>
+__attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+__global__ void __launch_bounds__(64) k_extend_packet(DevScene sc, PathQueue q, const uint32_t *counts, HitBuffer hits, uint32_t *work, ExtendTuning tune,
+                                                       unsigned long long *visit_counters) {
+  __shared__ uint32_t st_ref[kPacketStack], st_lo[kPacketStack], st_hi[kPacketStack];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t root = sc.root;
+  const uint32_t home = blockIdx.x % kRegions;
+  const uint32_t waves_per_region = gridDim.x / kRegions;
+  uint32_t nn = 0, nl = 0, wn = 0, wl = 0;
+  for (uint32_t region_try = 0; region_try < kRegions; region_try++) {  // own region first, then the others
+    const uint32_t r = (home + region_try) % kRegions;
+    const uint32_t r_count = counts[r * kCounterStride];
+    for (;;) {
+      // ---- claim (as k_extend does: the last claims of a region are smaller)
+      uint32_t claim = (uint32_t)tune.claim, off = r_count;
+      const uint32_t taken = *(volatile uint32_t *)&work[r * kCounterStride];
+      if (taken < r_count) {
+        const uint32_t left = r_count - taken;
+        if (tune.tail >= 1 && left < waves_per_region * claim) claim = left < waves_per_region * (claim / 4) ? max(64u, claim / 8) : max(64u, claim / 4);
+        if (lane == 0) off = atomicAdd(&work[r * kCounterStride], claim);
+        off = __shfl(off, 0);
+      }
+      if (off >= r_count) break;
+      const uint32_t w_end = r * q.cap + min(off + claim, r_count);
+      for (uint32_t p0 = r * q.cap + off; p0 < w_end; p0 += 64) {
+        // ---- one packet: the lane's ray
+        const uint32_t j = p0 + lane;
+        bool mine = j < w_end;
+        d3 ro = D3(0, 0, 0), rd = D3(0, 0, 1);
+        if (mine) {
+          if (tune.shared_origin) ro = ld3(sc.camera.camera_center);
+          else ro = D3(__builtin_nontemporal_load(&q.ox[j]), __builtin_nontemporal_load(&q.oy[j]), __builtin_nontemporal_load(&q.oz[j]));
+          rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
+        }
+        const RayP f = make_rayp(ro, rd);
+        Traversal tv;
+        trav_begin(root, tv);
+        bool walks = mine;
+        if (mine && !(root & kRefLeaf) && ray_has_negative_zero(rd)) walks = false;  // a miss (see ray_has_negative_zero)
+        if (mine && tune.pass == 1 && hits_danger_box(sc, ro, rd)) {  // left to the pass that follows the reference's rule
+          hits.ref[j] = kPending;
+          mine = walks = false;
+        }
+        uint32_t cur = root;
+        unsigned long long cmask = __ballot(walks);
+        int sp = 0;
+        while (cmask != 0ull) {
+          const bool in = (cmask >> lane) & 1ull;
+          bool pop = false;
+          if (!(cur & kRefLeaf)) {
+            const u32x16 n = scalar_load_node(sc.nodes, cur & kRefIndexMask);
+            float tl = 0.f, tr = 0.f;
+            const bool hl = in && slab_hit_p(__uint_as_float(n[0]), __uint_as_float(n[1]), __uint_as_float(n[2]), __uint_as_float(n[3]),
+                                               __uint_as_float(n[4]), __uint_as_float(n[5]), f, tv.tcull, tl);
+            const bool hr = in && slab_hit_p(__uint_as_float(n[6]), __uint_as_float(n[7]), __uint_as_float(n[8]), __uint_as_float(n[9]),
+                                               __uint_as_float(n[10]), __uint_as_float(n[11]), f, tv.tcull, tr);
+            const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+            const uint32_t left = n[12], right = n[13];
+            if (COUNT) { nn += in; wn++; }
+            if (ml != 0ull && mr != 0ull) {
+              // the child that more lanes meet first is entered first; the other waits with the lanes that hit it
+              const int want_left = __popcll(__ballot(hl && (!hr || tl <= tr))), want_right = __popcll(__ballot(hr && (!hl || tr < tl)));
+              const bool left_first = want_left >= want_right;
+              const unsigned long long later = left_first ? mr : ml;
+              if (lane == 0) {
+                st_ref[sp] = left_first ? right : left;
+                st_lo[sp] = (uint32_t)later;
+                st_hi[sp] = (uint32_t)(later >> 32);
+              }
+              sp++;
+              cur = left_first ? left : right;
+              cmask = left_first ? ml : mr;
+            } else if ((ml | mr) != 0ull) {
+              cur = ml != 0ull ? left : right;
+              cmask = ml | mr;
+            } else {
+              pop = true;
+            }
+          } else {
+            // a leaf, the same for every lane of the packet: the lanes that hit its box test it
+            const uint32_t kind = (cur >> kRefKindShift) & 3u;
+            if (COUNT) { nl += in; wl++; }
+            if (in) {
+              if (kind == RT_PRIM_TRIANGLE) trav_test_triangle_fast(sc, ro, rd, tv, cur);
+              else if (kind == RT_PRIM_QUAD) trav_test_quad_fast(sc, ro, rd, tv, cur);
+              else trav_test_sphere_fast(sc, ro, rd, tv, cur);
+            }
+            pop = true;
+          }
+          if (pop) {
+            if (sp == 0) break;
+            sp--;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_ref[sp]);
+            cmask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)st_lo[sp]) |
+                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)st_hi[sp]) << 32);
+          } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
+        }
+        if (mine) {
+          __builtin_nontemporal_store(tv.best.t, &hits.t[j]);
+          __builtin_nontemporal_store(tv.best.ref, &hits.ref[j]);
+        }
+      }
+    }
+  }
+  if (COUNT) {
+    atomicAdd(&visit_counters[0], (unsigned long long)nn);
+    atomicAdd(&visit_counters[1], (unsigned long long)nl);
+    if (lane == 0) {
+      atomicAdd(&visit_counters[3], (unsigned long long)wn);
+      atomicAdd(&visit_counters[4], (unsigned long long)wl);
+    }
+  }
+}
+
 // Tuning of a scene handle.  Read from the environment ONCE PER HANDLE, when rt_hip_scene_upload / rt_hip_scene_build make it
 // (the variable names are in the table below), changed afterwards with rt_hip_scene_tune; no render and no query reads the
 // environment, so what a handle does never depends on what ran before it in the process.
@@ -586,6 +723,9 @@ struct Tuning {
   int tile_hlog = -1;    // log2 of the tile height in shard rows; -1: by the row stride
   int spill_above = kSpillAboveDepth;  // tree height above which the binary walks keep only the newest kOvfLevels stack entries in LDS
   int verbose = 0;
+  int packet_waves = 7;  // waves per SIMD of the packet walk: the walk waits for one record after another (headline image, bounce 0:
+                         // 90.8 / 84.7 / 81.8 / 95.3 ms at 5 / 6 / 7 / 8 waves; eight spill inside the loop)
+  int packet = 1;        // bounce 0 by the packet walk (k_extend_packet): 64 neighbouring primary rays walk the tree together
   // layout of the device copy, used while the handle is made only
   int wide = -1, tri_pad = -1;  // -1: by size; 0 / 1: forced off / on
   int node_order = -1;          // -1: by size; 0: the reference's preorder; 1: line-sized blocks
@@ -605,6 +745,8 @@ static const TuningName kTuningNames[] = {
     {"RT_HIP_FIRST_GROUP", "first_group", &Tuning::first_group, 1, 1 << 20, false},
     {"RT_HIP_TILE_HLOG", "tile_hlog", &Tuning::tile_hlog, 0, 2 * RT_TILE_LOG, false},
     {"RT_HIP_VERBOSE", "verbose", &Tuning::verbose, 0, 1, false},
+    {"RT_HIP_PACKET", "packet", &Tuning::packet, 0, 1, false},
+    {"RT_HIP_PACKET_WAVES", "packet_waves", &Tuning::packet_waves, 5, 8, false},
     {"RT_HIP_SPILL_ABOVE", "spill_above", &Tuning::spill_above, kOvfLevels, kMaxStackDepth, true},
     {"RT_HIP_WIDE", "wide", &Tuning::wide, 0, 1, true},
     {"RT_HIP_TRI_PAD", "tri_pad", &Tuning::tri_pad, 0, 1, true},
@@ -712,12 +854,33 @@ static void launch_extend_pass(const DevScene &sc, const Tuning &tuning, bool qu
 // `counts` = entries per region; `work`, `work2` = claim counters per region of the (up to) two
 // passes, zeroed by the caller; all kCounterStride words apart.
 // `shared_origin`: the queue holds the primary rays k_generate wrote for a camera without a lens (no origins stored).
+// `coherent`: neighbouring entries of the queue are nearly the same ray (primary rays): the order-free walk is then done by
+// k_extend_packet, 64 rays at a time together (same results; the reference-rule walk has no such form).
+static void launch_extend_packet(const DevScene &sc, const Tuning &tuning, bool counted, int pass, bool shared_origin, int64_t n_upper, hipStream_t st,
+                                 PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, unsigned long long *visit_counters) {
+  ExtendTuning tune = tuning.extend;
+  tune.pass = pass;
+  tune.shared_origin = shared_origin;
+  int64_t claims = (n_upper + tune.claim - 1) / tune.claim;
+  int grid = (int)std::max<int64_t>(kRegions, std::min<int64_t>((claims + kRegions - 1) / kRegions * kRegions, kMaxExtendWaves));
+#define RT_LAUNCH_PACKET(C, W) hipLaunchKernelGGL((k_extend_packet<C, W>), dim3(grid), dim3(64), 0, st, sc, q, count_ptr, hits, work, tune, visit_counters)
+  if (counted) RT_LAUNCH_PACKET(true, 5);
+  else if (tuning.packet_waves >= 8) RT_LAUNCH_PACKET(false, 8);
+  else if (tuning.packet_waves == 7) RT_LAUNCH_PACKET(false, 7);
+  else if (tuning.packet_waves == 6) RT_LAUNCH_PACKET(false, 6);
+  else RT_LAUNCH_PACKET(false, 5);
+#undef RT_LAUNCH_PACKET
+}
 static void launch_extend(const DevScene &sc, const Tuning &tuning, int mode, bool counted, bool shared_origin, int64_t n_upper, hipStream_t st,
                           PathQueue q, const uint32_t *count_ptr, HitBuffer hits, uint32_t *work, uint32_t *work2,
-                          unsigned long long *visit_counters) {
+                          unsigned long long *visit_counters, bool coherent = false) {
+  const bool packet = coherent && tuning.packet && mode != 1;
   if (mode == 2) {
-    launch_extend_pass(sc, tuning, false, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    if (packet) launch_extend_packet(sc, tuning, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
+    else launch_extend_pass(sc, tuning, false, counted, 1, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
     launch_extend_pass(sc, tuning, true, counted, 2, shared_origin, n_upper, st, q, count_ptr, hits, work2, visit_counters);
+  } else if (packet) {
+    launch_extend_packet(sc, tuning, counted, 0, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
   } else {
     launch_extend_pass(sc, tuning, mode == 1, counted, 0, shared_origin, n_upper, st, q, count_ptr, hits, work, visit_counters);
   }
@@ -2631,10 +2794,10 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
         HIP_TRY(mark_begin(0, k));
         if (shared_rays)
           launch_extend(h->dev, h->tuning, walk, counted, true, (int64_t)ns * S, st, primary_q, primary_counts, primary_hits, primary_work, primary_work2,
-                        totals + RT_MAX_DEPTH_STATS + 1);
+                        totals + RT_MAX_DEPTH_STATS + 1, true);
         else
           launch_extend(h->dev, h->tuning, walk, counted, k == 0 && h->dev.camera.defocus_angle <= 0.0, np, st, q[k & 1], qcounts + k * per_bounce, hits, work + k * per_bounce,
-                        work2 + k * per_bounce, totals + RT_MAX_DEPTH_STATS + 1);
+                        work2 + k * per_bounce, totals + RT_MAX_DEPTH_STATS + 1, k == 0);
         LAUNCHED("k_extend");
         HIP_TRY(mark_end());
         HIP_TRY(mark_begin(1, k));
@@ -2786,7 +2949,9 @@ static int scene_tune_impl(RtSceneHandle *h, const char *name, int64_t value) {
   return fail(RT_ERR_BAD_ARG, std::string("no tuning parameter named ") + name);
 }
 
-static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, uint32_t *d_counts, int32_t flags, int32_t *prim_id, double *t) {
+// `coherent`: the queue holds primary rays in pixel order (see launch_extend)
+static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, uint32_t *d_counts, int32_t flags, int32_t *prim_id, double *t,
+                       bool coherent = false) {
   const size_t entries = (size_t)q.cap * kRegions;
   HitBuffer hits;
   int32_t *d_id;
@@ -2797,7 +2962,8 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   HIP_TRY(sc.alloc(&d_t, (size_t)n));
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
-  launch_extend(h->dev, h->tuning, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr);
+  launch_extend(h->dev, h->tuning, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr,
+                coherent);
   LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
   LAUNCHED("k_hits_to_elements");
@@ -2837,7 +3003,7 @@ static int primary_hits_impl(RtSceneHandle *h, const RtConfig *cfg, int32_t *pri
   if (rc != RT_OK) return rc;
   hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, 256, 2048)), dim3(256), 0, h->stream, h->dev, rp, q, d_count);
   LAUNCHED("k_primary_rays");
-  return trace_queue(h, sc, n, q, d_count, cfg->flags, prim_id, t);
+  return trace_queue(h, sc, n, q, d_count, cfg->flags, prim_id, t, true);  // the walk a render's first bounce takes
 }
 
 static int trace_rays_impl(RtSceneHandle *h, int64_t n, const double *origins, const double *directions, int32_t *prim_id, double *t) {
