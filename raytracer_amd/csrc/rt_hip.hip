@@ -590,6 +590,18 @@ RT_DEV u32x16 scalar_load_node(const DevNode *nodes, uint32_t index) {  // `inde
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(address) : "memory");
   return v;
 }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// The 72 bytes of a triangle record that the test reads (v0, e1, e2), the same for every lane.
+RT_DEV void scalar_load_triangle(const DevScene &sc, uint32_t index, d3 &v0, d3 &e1, d3 &e2) {
+  const uint64_t address = reinterpret_cast<uint64_t>(sc.triangles) + (uint64_t)__builtin_amdgcn_readfirstlane(index) * sc.tri_stride;
+  u32x16 a;
+  u32x4 b;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(address) : "memory");
+  auto f64 = [](uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+  v0 = D3(f64(a[0], a[1]), f64(a[2], a[3]), f64(a[4], a[5]));
+  e1 = D3(f64(a[6], a[7]), f64(a[8], a[9]), f64(a[10], a[11]));
+  e2 = D3(f64(a[12], a[13]), f64(a[14], a[15]), f64(b[0], b[1]));
+}
 constexpr int kPacketStack = kMaxStackDepth + 2;
 template <bool COUNT, int WAVES>
 __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
@@ -674,9 +686,17 @@ __global__ void __launch_bounds__(64) k_extend_packet(DevScene sc, PathQueue q, 
             // a leaf, the same for every lane of the packet: the lanes that hit its box test it
             const uint32_t kind = (cur >> kRefKindShift) & 3u;
             if (COUNT) { nl += in; wl++; }
-            if (in) {
-              if (kind == RT_PRIM_TRIANGLE) trav_test_triangle_fast(sc, ro, rd, tv, cur);
-              else if (kind == RT_PRIM_QUAD) trav_test_quad_fast(sc, ro, rd, tv, cur);
+            if (kind == RT_PRIM_TRIANGLE) {
+              d3 v0, e1, e2;
+              scalar_load_triangle(sc, cur & kRefIndexMask, v0, e1, e2);
+              if (in) {
+                const Ray ray = {ro, rd, D3(0, 0, 0)};
+                double t;
+                const bool ok = triangle_hit(v0, e1, e2, ray, kTMin, tv.best.t, t);
+                trav_accept_fast(sc, tv, cur, ok, t);
+              }
+            } else if (in) {
+              if (kind == RT_PRIM_QUAD) trav_test_quad_fast(sc, ro, rd, tv, cur);
               else trav_test_sphere_fast(sc, ro, rd, tv, cur);
             }
             pop = true;
