@@ -745,7 +745,8 @@ struct Tuning {
   int verbose = 0;
   int packet_waves = 7;  // waves per SIMD of the packet walk: the walk waits for one record after another (headline image, bounce 0:
                          // 90.8 / 84.7 / 81.8 / 95.3 ms at 5 / 6 / 7 / 8 waves; eight spill inside the loop)
-  int packet = 1;        // bounce 0 by the packet walk (k_extend_packet): 64 neighbouring primary rays walk the tree together
+  int packet = 1;        // bounce 0 by the packet walk (k_extend_packet): 64 neighbouring primary rays walk the tree together;
+                         // 2 (for measurements): the rays of rt_hip_trace_rays too, whatever they are
   // layout of the device copy, used while the handle is made only
   int wide = -1, tri_pad = -1;  // -1: by size; 0 / 1: forced off / on
   int node_order = -1;          // -1: by size; 0: the reference's preorder; 1: line-sized blocks
@@ -765,7 +766,7 @@ static const TuningName kTuningNames[] = {
     {"RT_HIP_FIRST_GROUP", "first_group", &Tuning::first_group, 1, 1 << 20, false},
     {"RT_HIP_TILE_HLOG", "tile_hlog", &Tuning::tile_hlog, 0, 2 * RT_TILE_LOG, false},
     {"RT_HIP_VERBOSE", "verbose", &Tuning::verbose, 0, 1, false},
-    {"RT_HIP_PACKET", "packet", &Tuning::packet, 0, 1, false},
+    {"RT_HIP_PACKET", "packet", &Tuning::packet, 0, 2, false},
     {"RT_HIP_PACKET_WAVES", "packet_waves", &Tuning::packet_waves, 5, 8, false},
     {"RT_HIP_SPILL_ABOVE", "spill_above", &Tuning::spill_above, kOvfLevels, kMaxStackDepth, true},
     {"RT_HIP_WIDE", "wide", &Tuning::wide, 0, 1, true},
@@ -2983,7 +2984,7 @@ static int trace_queue(RtSceneHandle *h, Scratch &sc, int64_t n, PathQueue q, ui
   const int block = 256;
   uint32_t *work = d_counts + (size_t)kRegions * kCounterStride;
   launch_extend(h->dev, h->tuning, walk_mode(h, flags), false, false, n, h->stream, q, d_counts, hits, work, work + (size_t)kRegions * kCounterStride, nullptr,
-                coherent);
+                coherent || h->tuning.packet == 2);
   LAUNCHED("k_extend");
   hipLaunchKernelGGL(k_hits_to_elements, dim3(grid_for(n, block, 2048)), dim3(block), 0, h->stream, h->dev, n, q.cap, hits, d_id, d_t);
   LAUNCHED("k_hits_to_elements");

@@ -68,10 +68,13 @@ def main():
     rays_traced = bench["rays_traced_per_step_rank0"] * bench["steps"]
     rays = bench["rays_per_step"] * bench["steps"]
 
+    def member(k, prefix):  # k_extend stands for both walks of the closest-hit step: the general one and the packet walk of bounce 0
+        return k == prefix or k.startswith(prefix + "<") or (prefix == "k_extend" and k.startswith("k_extend_packet<"))
+
     def family(prefix):  # all instantiations of a kernel template that ran in the profiled render
         tot = collections.defaultdict(float)
         for k, v in out.items():
-            if k == prefix or k.startswith(prefix + "<"):
+            if member(k, prefix):
                 for c, x in v.items():
                     tot[c] += x
         return dict(tot)
@@ -82,8 +85,8 @@ def main():
         if fam:
             # the instantiations the timed renders launch: k_extend's second template argument marks the counting build,
             # which only the one instrumented render of a bench run uses
-            ms = [v for k, v in kernel_ms.items() if (k == name or k.startswith(name + "<")) and not k.startswith(name + "<false, true")
-                  and not k.startswith(name + "<true, true")]
+            ms = [v for k, v in kernel_ms.items() if member(k, name) and not k.startswith(name + "<false, true")
+                  and not k.startswith(name + "<true, true") and not k.startswith("k_extend_packet<true")]
             if ms:
                 fam["kernel_avg_launch_ms"] = sum(m["total_ms"] for m in ms) / max(sum(m["calls"] for m in ms), 1)
             kernels[name] = fam
