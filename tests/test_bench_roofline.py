@@ -41,3 +41,11 @@ def test_counters_follow_this_runs_kernel_time_within_bounds():
     assert abs(slower["valu_busy"] - 0.5 / 1.05) < 1e-12  # the same instructions over 5 % more time
     off = bench.counter_roofline(inputs, 100.0, 560.0 * 1.3, 0.0, 0.5, extend_launches=56)
     assert "k_extend" not in off and "more than" in off["refused"]
+
+
+def test_committed_counter_sums_name_their_build():
+    with open(os.path.join(ROOT, "profiles", "roofline_inputs.json")) as f:
+        inputs = json.load(f)
+    assert "source_hash" in inputs and len(inputs["source_hash"]) == 16
+    # the counters must be those of the kernels in this tree: after a change to them, run the profile round again
+    assert inputs["source_hash"] == abi.kernel_source_hash(), "profiles/roofline_inputs.json is stale: tools/profile_round.sh + tools/summarize_profiles.py"

@@ -9,7 +9,7 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/stats.json 2> $O/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-reuse-leg > $O/stats.json 2> $O/stats.err
 pass() {  # name, counters...
   n=$1; shift
   timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -- python3 $R/bench.py --profile-pass > $O/pmc_$n.json 2> $O/pmc_$n.err
