@@ -561,6 +561,7 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   h->bvh_depth = tree_height;
   h->n_internal = n_internal;
   h->device_built = true;
+  resolve_packet_default(h);
   if ((rc = noalloc_warm_up(h)) != RT_OK) return rc;
   if (verbose) {
     auto now = std::chrono::steady_clock::now();

@@ -746,3 +746,56 @@ def test_zero_area_triangles_can_lose_the_references_noise_hit_but_nothing_is_in
     a, b = dirty.resident(0).primary_hits(rule)
     c, e = oracle.primary_hits(dirty.scene, rule)
     assert np.array_equal(a, c) and np.array_equal(b, e)
+
+
+@pytest.mark.parametrize("defocus", [0.0, 1.2])
+def test_packet_walk_and_general_walk_give_the_same_hits_and_images(tmp_scene_dir, defocus):
+    """Bounce 0 is walked by the wave as a whole on small trees (k_extend_packet) and lane by lane on large ones; which of
+    the two runs must not show in any result.  Also with a lens (every ray of a packet has its own origin), on rows of a shard
+    (packets that end inside a claim), with the scene's tilted-quad pass and with more rays than one claim per wave."""
+    ri = knot_scene(tmp_scene_dir, 20000, 97, 61, 12, 5, 1, defocus=defocus)
+    res = ri.resident(0)
+    cfg = ri.config.copy()
+    outs = []
+    for packet in (1, 0):
+        res.tune(packet=packet)
+        prim, t = res.primary_hits(cfg)
+        img, st = res.render(cfg)
+        shard = cfg.copy()
+        shard.row_first, shard.row_stride = 2, 5
+        part, _ = res.render(shard)
+        counted = cfg.copy()
+        counted.flags = abi.RT_FLAG_COUNT_VISITS
+        _, sc_ = res.render(counted)
+        outs.append((prim, t, img, int(st.rays), part, sc_))
+    res.tune(packet=1)
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k]) and np.array_equal(a[4][k], b[4][k]), k
+    assert a[3] == b[3]
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    assert np.array_equal(a[0], po) and np.array_equal(a[1], to)
+    # the counting builds of both walks count: a packet's lane visits a node when it is among the lanes the node was entered for
+    assert a[5].node_visits > 0 and a[5].leaf_tests > 0 and a[5].rays_traced == b[5].rays_traced
+    assert 0.5 * b[5].node_visits < a[5].node_visits < 1.5 * b[5].node_visits
+
+
+def test_packet_walk_on_a_scene_with_stray_quads_and_on_a_single_leaf():
+    from raytracer_amd import RenderIntegrator, scenes
+    ri = _tilted_quad_scene()
+    res = ri.resident(0)
+    cfg = ri.config.copy()
+    got = []
+    for packet in (1, 0):
+        res.tune(packet=packet)
+        got.append(res.primary_hits(cfg) + (res.render(cfg)[0]["linear"],))
+    assert all(np.array_equal(x, y) for x, y in zip(*got))
+    po, to = oracle.primary_hits(ri.scene, cfg)
+    assert np.array_equal(got[0][0], po) and np.array_equal(got[0][1], to)
+    one = RenderIntegrator.new({"camera": scenes.camera(), "elements": [scenes.sphere((278, 278, 200), 120, scenes.lambertian(.5, .5, .5))]},
+                               scenes.config(16, 16, 2, 1, 1)).prepare()
+    r1 = one.resident(0).tune(packet=1)
+    p1, t1 = r1.primary_hits(one.config.copy())
+    po, to = oracle.primary_hits(one.scene, one.config.copy())
+    assert np.array_equal(p1, po) and np.array_equal(t1, to)
