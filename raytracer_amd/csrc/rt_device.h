@@ -754,13 +754,13 @@ RT_DEV void trav_pop(Traversal &tv, const uint32_t *stack, int stride) {
 // (trav_test_leaf breaks ties by the reference's leaf order).  Enter the nearer child first and
 // drop children that begin beyond the closest hit so far.
 template <int SPILL>
-RT_DEV void trav_node_fast(const DevScene &sc, const RayF &f, Traversal &tv, const StackRef &stack) {
+RT_DEV void trav_node_fast(const DevScene &sc, const RayP &f, Traversal &tv, const StackRef &stack) {
   const float4 *p = reinterpret_cast<const float4 *>(&sc.nodes[tv.cur & kRefIndexMask]);
   float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
   uint32_t left = __float_as_uint(q3.x), right = __float_as_uint(q3.y);
   float tl, tr;
-  bool hl = slab_hit_f32(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tv.tcull, tl);
-  bool hr = slab_hit_f32(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
+  bool hl = slab_hit_p(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tv.tcull, tl);
+  bool hr = slab_hit_p(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tv.tcull, tr);
   if (hl && hr) {
     bool swap = tr < tl;
     stack_push<SPILL>(tv, stack, swap ? left : right);

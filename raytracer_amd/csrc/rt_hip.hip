@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
   uint32_t j = kNoRay;
   d3 ro = D3(0, 0, 0), rd = D3(0, 0, 1);
   RayF f = {};
+  RayP fp = {};
   RayQ fq = {};
   d3 rinv = D3(0, 0, 0);  // 1 / direction in f64: the walk on the reference's own boxes (QUIRK with DevNodeD records)
   Traversal tv;
@@ -445,7 +446,8 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           rd = D3(__builtin_nontemporal_load(&q.dx[j]), __builtin_nontemporal_load(&q.dy[j]), __builtin_nontemporal_load(&q.dz[j]));
           if (WIDE) fq = make_rayq<true>(sc, ro, rd);
           else if (GRID) fq = make_rayq(sc, ro, rd);
-          else f = make_rayf(ro, rd);
+          else if (QUIRK) f = make_rayf(ro, rd);
+          else fp = make_rayp(ro, rd);
           if (QUIRK && sc.nodes_d) rinv = D3(1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z);  // ray.rs:38-41
           trav_begin(root, tv);
           if (!(root & kRefLeaf) && ray_has_negative_zero(rd)) tv.cur = kDone;  // retires below as a miss
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
         else if (QUIRK) trav_node_ref(sc, f, tv, stack, stride);
         else if (WIDE) trav_node_w<SM>(sc, fq, tv, sref, leafq, tune.leafq);
         else if (GRID) trav_node_q<SM>(sc, fq, tv, sref);
-        else trav_node_fast<SM>(sc, f, tv, sref);
+        else trav_node_fast<SM>(sc, fp, tv, sref);
       }
       if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) {
         if (QUIRK) trav_defer_leaf<true>(tv, stack, leafq, stride);
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(64) k_extend(DevScene sc, PathQueue q, const u
           if (COUNT) nn++;
           if (WIDE) trav_node_w<SM>(sc, fq, tv, sref, leafq, tune.leafq);
           else if (GRID) trav_node_q<SM>(sc, fq, tv, sref);
-          else trav_node_fast<SM>(sc, f, tv, sref);
+          else trav_node_fast<SM>(sc, fp, tv, sref);
         }
         if ((tv.cur & kRefLeaf) && tv.cur < kWait && tv.qn < tune.leafq) trav_defer_leaf_fast<SM, kLdsl>(tv, sref, leafq);
       }
