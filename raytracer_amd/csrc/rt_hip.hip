@@ -659,9 +659,9 @@ __global__ void __launch_bounds__(64) k_extend_packet(DevScene sc, PathQueue q, 
             const u32x16 n = scalar_load_node(sc.nodes, cur & kRefIndexMask);
             float tl = 0.f, tr = 0.f;
             const bool hl = in && slab_hit_p(__uint_as_float(n[0]), __uint_as_float(n[1]), __uint_as_float(n[2]), __uint_as_float(n[3]),
-                                               __uint_as_float(n[4]), __uint_as_float(n[5]), f, tv.tcull, tl);
+                                             __uint_as_float(n[4]), __uint_as_float(n[5]), f, tv.tcull, tl);
             const bool hr = in && slab_hit_p(__uint_as_float(n[6]), __uint_as_float(n[7]), __uint_as_float(n[8]), __uint_as_float(n[9]),
-                                               __uint_as_float(n[10]), __uint_as_float(n[11]), f, tv.tcull, tr);
+                                             __uint_as_float(n[10]), __uint_as_float(n[11]), f, tv.tcull, tr);
             const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
             const uint32_t left = n[12], right = n[13];
             if (COUNT) { nn += in; wn++; }

@@ -799,3 +799,31 @@ def test_packet_walk_on_a_scene_with_stray_quads_and_on_a_single_leaf():
     p1, t1 = r1.primary_hits(one.config.copy())
     po, to = oracle.primary_hits(one.scene, one.config.copy())
     assert np.array_equal(p1, po) and np.array_equal(t1, to)
+
+
+def test_tuning_parameters_are_per_handle_and_validated(monkeypatch):
+    """rt_hip_scene_tune: unknown names, layout parameters and values out of range are refused; a handle reads the
+    environment when it is made and never again."""
+    from raytracer_amd.integrator import ResidentScene
+    ri = c1(width=16, height=16, batch=4, max_batches=9, min_batches=0)
+    res = ri.resident(0)
+    lib = abi.hip_lib()
+    for name, value in ((b"no_such_knob", 1), (b"wide", 1), (b"spill_above", 20), (b"refill", 0), (b"refill", 65), (b"packet_waves", 4), (b"max_paths", -1)):
+        assert lib.rt_hip_scene_tune(res._h, name, value) == abi.RT_ERR_BAD_ARG, name
+        assert lib.rt_hip_last_error()
+    assert lib.rt_hip_scene_tune(None, b"refill", 40) == abi.RT_ERR_BAD_ARG
+    cfg = ri.config.copy()
+    base, st0 = res.render(cfg)
+    res.tune(refill=16, node_min=8, leafq=2, claim=128, tail=3, shade_blocks=64, max_group=2, first_group=2, packet=0, tile_hlog=1)
+    tuned, st1 = res.render(cfg)
+    for k in base:
+        assert np.array_equal(base[k], tuned[k]), k
+    assert st1.rays == st0.rays and st1.batches > st0.batches  # smaller rounds, same image
+    # the environment is read when a handle is made, not while it renders
+    monkeypatch.setenv("RT_HIP_MAX_GROUP", "1")
+    _, st2 = res.render(cfg)
+    assert st2.batches == st1.batches
+    other = ResidentScene(ri.scene, 0)
+    _, st3 = other.render(cfg)
+    assert st3.batches == cfg.max_sample_batches  # one batch per round on the handle made under the variable
+    other.close()
