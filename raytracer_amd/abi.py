@@ -240,7 +240,7 @@ def host_lib():
     return _host
 
 
-KERNEL_SOURCES = ("csrc/rt_hip.hip", "csrc/rt_device.h", "csrc/rt_build_device.h")
+KERNEL_SOURCES = ("csrc/rt_hip.hip", "csrc/rt_device.h", "csrc/rt_build_device.h", "csrc/rt_build_topdown.h")
 
 
 def kernel_source_hash():

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_prim_bounds(int32_t n, const RtElementR
         b.mx[a] = up32(hi[a]);
       }
       if (!finite) {
-        atomicOr(bad, 1u);
+        atomicOr(bad, 0x100u);
         for (int a = 0; a < 3; a++) b.mn[a] = b.mx[a] = 0.0f, lo[a] = hi[a] = 0.0;
       }
       boxes[e] = b;
@@ -181,15 +181,137 @@ __global__ void __launch_bounds__(256) k_refit_pass(int32_t n_internal, const ui
   }
 }
 
+// ---------------------------------------------------------------- agglomerative build
+// The tree by parallel locally-ordered clustering (Meister and Bittner 2018) instead of the radix tree: the clusters -- at first
+// the primitives, in Morton order -- each look for the neighbour within `radius` places whose union with them has the smallest
+// surface area; two clusters that choose each other become the children of a new node, which takes the place of the first of
+// them; the rest stay; repeated until one cluster is left.  Nearby clusters merge by what their union costs, not by where the
+// Morton code's bits happen to split space, which is what the surface-area heuristic of the reference's builder asks for too
+// (bvh_node_sah.rs:385-461).  One iteration is three launches and a prefix sum, and its only hand-off is the kernel boundary.
+constexpr int kPlocBlock = 256, kPlocMaxRadius = 32;
+constexpr uint32_t kNoParent = 0xffffffffu;
+
+RT_DEV float union_half_area(const Box32 &a, const Box32 &b) {  // never NaN: extents are finite and >= 0 (a product may overflow to +inf)
+  const float dx = fmaxf(a.mx[0], b.mx[0]) - fminf(a.mn[0], b.mn[0]);
+  const float dy = fmaxf(a.mx[1], b.mx[1]) - fminf(a.mn[1], b.mn[1]);
+  const float dz = fmaxf(a.mx[2], b.mx[2]) - fminf(a.mn[2], b.mn[2]);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(256) k_ploc_init(int32_t n, const uint32_t *ids, const Box32 *prim_boxes, uint32_t *cl_ref, Box32 *cl_box) {
+  for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    cl_ref[j] = kChildLeaf | (uint32_t)j;
+    cl_box[j] = prim_boxes[ids[j]];
+  }
+}
+
+// nn[i] = the cluster within `radius` places of i whose union with i is smallest (the lower place among equals; c >= 2).
+// The relation is symmetric and the order total, so the pair with the globally smallest union that involves the lowest place
+// always chooses each other: every iteration merges at least one pair.
+__global__ void __launch_bounds__(kPlocBlock) k_ploc_nearest(uint32_t c, int radius, const Box32 *cl_box, uint32_t *nn) {
+  __shared__ Box32 tile[kPlocBlock + 2 * kPlocMaxRadius];
+  for (uint32_t base = blockIdx.x * kPlocBlock; base < c; base += gridDim.x * kPlocBlock) {  // the same trips for every thread of the block
+    __syncthreads();
+    for (int k = threadIdx.x; k < kPlocBlock + 2 * radius; k += kPlocBlock) {
+      const int64_t g = (int64_t)base - radius + k;
+      if (g >= 0 && g < (int64_t)c) tile[k] = cl_box[g];
+    }
+    __syncthreads();
+    const uint32_t i = base + threadIdx.x;
+    if (i < c) {
+      const Box32 a = tile[threadIdx.x + radius];
+      float best = 0.0f;
+      uint32_t bj = i;
+      for (int k = -radius; k <= radius; k++) {
+        const int64_t j = (int64_t)i + k;
+        if (k == 0 || j < 0 || j >= (int64_t)c) continue;
+        const float d = union_half_area(a, tile[(int)threadIdx.x + radius + k]);
+        if (bj == i || d < best) {
+          best = d;
+          bj = (uint32_t)j;
+        }
+      }
+      nn[i] = bj;
+    }
+  }
+}
+
+// flags[i]: low word 1 if place i survives (alone, or as the new node of a pair), high word 1 if it is the first of a pair
+__global__ void __launch_bounds__(256) k_ploc_flags(uint32_t c, const uint32_t *nn, unsigned long long *flags) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == i;
+    flags[i] = (mutual && i > j ? 0ull : 1ull) | (mutual && i < j ? 1ull << 32 : 0ull);
+  }
+}
+
+struct PlocNodes {  // the tree under construction; node ids count up from 0 in the order of the merges
+  uint32_t *child_l, *child_r, *parent, *leaf_parent, *leaves;  // leaves[id]: primitives below node id
+  int32_t *height;
+  Box32 *box;
+};
+RT_DEV void ploc_adopt(const PlocNodes &t, uint32_t child, uint32_t id) {
+  if (child & kChildLeaf) t.leaf_parent[child & ~kChildLeaf] = id;
+  else t.parent[child] = id;
+}
+// `scan` = exclusive prefix sums of `flags`; pair k of this iteration becomes node node_base + k.  counts[0] = clusters left.
+__global__ void __launch_bounds__(256) k_ploc_merge(uint32_t c, uint32_t node_base, const uint32_t *nn, const unsigned long long *flags,
+                                                     const unsigned long long *scan, const uint32_t *ref_in, const Box32 *box_in, uint32_t *ref_out,
+                                                     Box32 *box_out, PlocNodes t, uint32_t *counts) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
+    const unsigned long long f = flags[i], s = scan[i];
+    if (i == c - 1) counts[0] = (uint32_t)s + (uint32_t)f;
+    if (!(uint32_t)f) continue;
+    const uint32_t dst = (uint32_t)s;
+    if (f >> 32) {
+      const uint32_t j = nn[i], id = node_base + (uint32_t)(s >> 32);
+      const uint32_t l = ref_in[i], r = ref_in[j];
+      const Box32 a = box_in[i], b = box_in[j];
+      Box32 u;
+      for (int ax = 0; ax < 3; ax++) u.mn[ax] = fminf(a.mn[ax], b.mn[ax]), u.mx[ax] = fmaxf(a.mx[ax], b.mx[ax]);
+      t.child_l[id] = l;
+      t.child_r[id] = r;
+      t.box[id] = u;
+      t.height[id] = 1 + max((l & kChildLeaf) ? 0 : t.height[l], (r & kChildLeaf) ? 0 : t.height[r]);
+      t.leaves[id] = ((l & kChildLeaf) ? 1u : t.leaves[l]) + ((r & kChildLeaf) ? 1u : t.leaves[r]);
+      t.parent[id] = kNoParent;
+      ploc_adopt(t, l, id);
+      ploc_adopt(t, r, id);
+      ref_out[dst] = id;
+      box_out[dst] = u;
+    } else {
+      ref_out[dst] = ref_in[i];
+      box_out[dst] = box_in[i];
+    }
+  }
+}
+
+// Position of every leaf in the depth-first, left-first order of the finished tree (what decides exact ties between
+// primitives): the leaves under the left siblings passed on the way up to the root.
+__global__ void __launch_bounds__(256) k_leaf_ranks(int32_t n, PlocNodes t, uint32_t *rank) {
+  for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    uint32_t from = kChildLeaf | (uint32_t)j, node = t.leaf_parent[j], before = 0;
+    while (node != kNoParent) {
+      const uint32_t l = t.child_l[node];
+      if (l != from) before += (l & kChildLeaf) ? 1u : t.leaves[l];
+      from = node;
+      node = t.parent[node];
+    }
+    rank[j] = before;
+  }
+}
+
 // Leaf refs and primitive records in leaf order.  `tri_pos[j]` = triangles before sorted position j;
-// `slot_in_kind[e]` = position of element e among the quad (sphere) elements, in element order.
+// `slot_in_kind[e]` = position of element e among the quad (sphere) elements, in element order;
+// `rank[j]` = place of the leaf in the tree's depth-first order (null: the sorted position itself, as in the radix tree).
 __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *ids, const uint32_t *tri_pos, const uint32_t *slot_in_kind,
                                                      const RtElementRef *elements, const RtTriangle *tris, const RtQuad *quads, const RtSphere *spheres,
                                                      DevTriangle *out_tris, uint32_t tri_stride, DevTriShade *out_shade, DevQuad *out_quads,
-                                                     DevSphere *out_spheres, uint32_t *leaf_ref) {
+                                                     DevSphere *out_spheres, uint32_t *leaf_ref, const uint32_t *rank) {
   for (int32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     uint32_t e = ids[j];
     RtElementRef er = elements[e];
+    const uint32_t leaf_rank = rank ? rank[j] : (uint32_t)j;
     uint32_t slot;
     if (er.kind == RT_PRIM_TRIANGLE) {
       slot = tri_pos[j];
@@ -199,7 +321,7 @@ __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *i
       d.e1[0] = t.v0v1.x; d.e1[1] = t.v0v1.y; d.e1[2] = t.v0v1.z;
       d.e2[0] = t.v0v2.x; d.e2[1] = t.v0v2.y; d.e2[2] = t.v0v2.z;
       d.element = e;
-      d.rank = (uint32_t)j;
+      d.rank = leaf_rank;
       *reinterpret_cast<DevTriangle *>(reinterpret_cast<char *>(out_tris) + (size_t)slot * tri_stride) = d;  // records tri_stride bytes apart
       DevTriShade sh;
       sh.normal[0] = t.normal.x; sh.normal[1] = t.normal.y; sh.normal[2] = t.normal.z;
@@ -219,7 +341,7 @@ __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *i
       d.area = q.area;
       d.element = e;
       d.material = (uint32_t)q.material;
-      d.rank = (uint32_t)j;
+      d.rank = leaf_rank;
       d.pad = 0;
       out_quads[slot] = d;
     } else {
@@ -230,7 +352,7 @@ __global__ void __launch_bounds__(256) k_emit_prims(int32_t n, const uint32_t *i
       d.radius = s.radius;
       d.element = e;
       d.material = (uint32_t)s.material;
-      d.rank = (uint32_t)j;
+      d.rank = leaf_rank;
       d.pad = 0;
       out_spheres[slot] = d;
     }
@@ -304,6 +426,8 @@ __global__ void __launch_bounds__(256) k_emit_nodes(int32_t n_internal, const ui
 }
 
 }  // namespace build
+
+#include "rt_build_topdown.h"
 
 // Scratch device memory of a build, freed on every way out.
 struct BuildTemps {
@@ -413,16 +537,95 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
 
   const int block = 256;
   const int grid = grid_for(n, block, 256 * 8);
+  const int gi = grid_for(std::max(n_internal, 1), block, 256 * 8);
+  // how the tree is made: 0 radix tree over Morton codes, 1 locally-ordered clustering, 2 / 3 the reference's own top-down
+  // build with its bucketed surface-area heuristic / its midpoint split (rt_build_topdown.h)
+  const int method = n_internal > 0 ? tuning.build_method : 0;
+  const bool topdown = method >= 2, ploc = method == 1;
   hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(block), 0, st, n, d_elements, d_tris, d_quads, d_spheres, d_boxes, d_scene, d_bad);
-  hipLaunchKernelGGL(k_morton, dim3(grid), dim3(block), 0, st, n, d_boxes, d_scene, d_keys[0], d_ids[0]);
   size_t sort_bytes = 0, scan_bytes = 0;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_keys[0], d_keys[1], d_ids[0], d_ids[1], n, 0, 63, st));
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_tri_pos, n, st));
   char *d_lib_tmp;
   HIP_TRY(tmp.alloc(&d_lib_tmp, std::max(sort_bytes, scan_bytes)));
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_lib_tmp, sort_bytes, d_keys[0], d_keys[1], d_ids[0], d_ids[1], n, 0, 63, st));
   const uint64_t *keys = d_keys[1];
-  const uint32_t *ids = d_ids[1];
+  const uint32_t *ids = d_ids[1];  // the elements in leaf order
+  int td_levels = 0;
+  if (!topdown) {
+    hipLaunchKernelGGL(k_morton, dim3(grid), dim3(block), 0, st, n, d_boxes, d_scene, d_keys[0], d_ids[0]);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_lib_tmp, sort_bytes, d_keys[0], d_keys[1], d_ids[0], d_ids[1], n, 0, 63, st));
+  } else {
+    // ---- the reference's top-down build, one level of the tree per trip
+    const int sah = method == 2 ? 1 : 0;
+    Rec64 *d_recs;
+    uint32_t *d_seg_of[2], *d_class_key, *d_n_left, *d_new_count, *d_base, *d_counts;
+    uint8_t *d_bins;
+    Cnt16 *d_before;
+    Box12 *d_class_box;
+    double *d_child_cb;
+    TdSegments sg[2];
+    HIP_TRY(tmp.alloc(&d_recs, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_bins, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_before, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_class_box, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_class_key, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_n_left, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_new_count, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_base, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_child_cb, 12 * (size_t)n));
+    HIP_TRY(tmp.alloc(&d_counts, 4));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(tmp.alloc(&d_seg_of[k], (size_t)n));
+      HIP_TRY(tmp.alloc(&sg[k].lo, (size_t)n));
+      HIP_TRY(tmp.alloc(&sg[k].cnt, (size_t)n));
+      HIP_TRY(tmp.alloc(&sg[k].node, (size_t)n));
+      HIP_TRY(tmp.alloc(&sg[k].active, (size_t)n));
+      HIP_TRY(tmp.alloc(&sg[k].cb, 6 * (size_t)n));
+    }
+    const TdTree tree{d_child_l, d_child_r};
+    rocprim::transform_iterator<const uint8_t *, OneHot16, Cnt16> one_hot(d_bins, OneHot16());
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    {
+      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> probe(d_ids[0], RecBox12{d_recs});
+      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, b1, d_seg_of[0], one_hot, d_before, Cnt16Sum(), n, hipcub::Equality(), st));
+      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, b2, d_class_key, probe, d_class_box, Box12Union(), n, hipcub::Equality(), st));
+      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b3, d_new_count, d_base, n, st));
+    }
+    char *d_td_tmp;
+    HIP_TRY(tmp.alloc(&d_td_tmp, std::max(b1, std::max(b2, b3))));
+    int cur = 0;  // d_ids[cur], d_seg_of[cur], sg[cur] describe the level about to be split
+    hipLaunchKernelGGL(k_td_element_recs, dim3(grid), dim3(block), 0, st, n, d_elements, d_tris, d_quads, d_spheres, d_recs, d_ids[0], d_seg_of[0]);
+    HIP_TRY(hipMemsetAsync(d_class_key, 0, (size_t)n * sizeof(uint32_t), st));
+    {
+      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> boxes_of(d_ids[0], RecBox12{d_recs});
+      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b2, d_class_key, boxes_of, d_class_box, Box12Union(), n, hipcub::Equality(), st));
+    }
+    hipLaunchKernelGGL(k_td_root, dim3(1), dim3(64), 0, st, n, d_class_box, sg[0], tree);
+    uint32_t n_seg = 1, n_active = n >= 3 ? 1u : 0u;
+    while (n_active > 0) {
+      if (++td_levels > 4 * kMaxStackDepth) return fail(RT_ERR_UNSUPPORTED, "the top-down device build does not terminate: use the host build for this scene");
+      const int gs = grid_for((int64_t)n_seg, block, 256 * 8);
+      hipLaunchKernelGGL(k_td_bins, dim3(grid), dim3(block), 0, st, n, sah, d_ids[cur], d_seg_of[cur], sg[cur], d_recs, d_bins, d_bad);
+      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b1, d_seg_of[cur], one_hot, d_before, Cnt16Sum(), n, hipcub::Equality(), st));
+      hipLaunchKernelGGL(k_td_scatter, dim3(grid), dim3(block), 0, st, n, d_ids[cur], d_seg_of[cur], sg[cur], d_bins, d_before, d_ids[cur ^ 1], d_class_key);
+      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> boxes_of(d_ids[cur ^ 1], RecBox12{d_recs});
+      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b2, d_class_key, boxes_of, d_class_box, Box12Union(), n, hipcub::Equality(), st));
+      hipLaunchKernelGGL(k_td_split, dim3(gs), dim3(block), 0, st, n_seg, sah, sg[cur], d_before, d_class_box, tree, d_n_left, d_child_cb, d_new_count, d_bad);
+      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_td_tmp, b3, d_new_count, d_base, (int)n_seg, st));
+      HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_td_segments, dim3(gs), dim3(block), 0, st, n_seg, sg[cur], d_n_left, d_child_cb, d_base, sg[cur ^ 1], d_counts);
+      hipLaunchKernelGGL(k_td_seg_of, dim3(grid), dim3(block), 0, st, n, d_seg_of[cur], sg[cur], d_n_left, d_base, d_seg_of[cur ^ 1]);
+      uint32_t counts[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipGetLastError());
+      if (counts[1] <= n_seg || counts[1] > (uint32_t)n) return fail(RT_ERR_HIP, "the top-down device build lost track of its ranges");
+      n_active = counts[0];
+      n_seg = counts[1];
+      cur ^= 1;
+    }
+    ids = d_ids[cur];
+  }
   hipLaunchKernelGGL(k_flag_triangles, dim3(grid), dim3(block), 0, st, n, ids, d_elements, d_flags);
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_lib_tmp, scan_bytes, d_flags, d_tri_pos, n, st));
 
@@ -442,8 +645,6 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   if ((rc = dev_alloc(h, &o_shade, n_tri_el)) != RT_OK || (rc = dev_alloc(h, &o_quads, n_quad_el)) != RT_OK ||
       (rc = dev_alloc(h, &o_spheres, n_sph_el)) != RT_OK)
     return rc;
-  hipLaunchKernelGGL(k_emit_prims, dim3(grid), dim3(block), 0, st, n, ids, d_tri_pos, d_slot, d_elements, d_tris, d_quads, d_spheres, o_tris, tri_stride,
-                     o_shade, o_quads, o_spheres, d_leaf_ref);
   h->dev.triangles = o_tris;
   h->dev.tri_stride = tri_stride;
   h->dev.tri_shade = o_shade;
@@ -454,7 +655,8 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   uint32_t scene_host[8];
   HIP_TRY(hipMemcpyAsync(scene_host, d_scene, sizeof scene_host, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (scene_host[6]) return fail(RT_ERR_UNSUPPORTED, "a primitive has a non-finite or enormous coordinate: the device build needs finite bounds");
+  if (scene_host[6] & 0x100u) return fail(RT_ERR_UNSUPPORTED, "a primitive has a non-finite or enormous coordinate: the device build needs finite bounds");
+  if (scene_host[6]) return fail(RT_ERR_UNSUPPORTED, "the top-down device build met a bucket index out of range or an empty child (a NaN coordinate?): use the host build for this scene");
   auto unordered = [](uint32_t u) {
     uint32_t bits = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
     float f;
@@ -475,13 +677,64 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   DevNode *o_nodes = nullptr;
   DevNodeQ *o_nodes_q = nullptr;
   if ((rc = dev_alloc(h, &o_nodes, (size_t)std::max(n_internal, 1))) != RT_OK) return rc;
-  if (n_internal == 0) {  // a single element: the root is its leaf
-    HIP_TRY(hipMemcpy(&root_ref, d_leaf_ref, sizeof root_ref, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(o_nodes, 0, sizeof(DevNode)));
+  uint32_t root_node = 0;
+  uint32_t *d_rank = nullptr;  // depth-first place of every leaf where it is not its sorted position
+  int ploc_iterations = 0;
+  // ---- the tree: children of every internal node, its box and its height
+  if (n_internal == 0) {
+    // a single element: the root is its leaf
+  } else if (ploc) {
+    PlocNodes t;
+    t.child_l = d_child_l;
+    t.child_r = d_child_r;
+    t.box = d_node_boxes;
+    t.height = d_height[0];
+    uint32_t *cl_ref[2], *d_nn, *d_counts;
+    Box32 *cl_box[2];
+    unsigned long long *d_pflags, *d_pscan;
+    HIP_TRY(tmp.alloc(&t.parent, (size_t)n_internal));
+    HIP_TRY(tmp.alloc(&t.leaf_parent, (size_t)n));
+    HIP_TRY(tmp.alloc(&t.leaves, (size_t)n_internal));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(tmp.alloc(&cl_ref[k], (size_t)n));
+      HIP_TRY(tmp.alloc(&cl_box[k], (size_t)n));
+    }
+    HIP_TRY(tmp.alloc(&d_nn, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_pflags, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_pscan, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_counts, 4));
+    HIP_TRY(tmp.alloc(&d_rank, (size_t)n));
+    size_t pscan_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, pscan_bytes, d_pflags, d_pscan, n, st));
+    char *d_pscan_tmp;
+    HIP_TRY(tmp.alloc(&d_pscan_tmp, pscan_bytes));
+    hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(block), 0, st, n, ids, d_boxes, cl_ref[0], cl_box[0]);
+    const int radius = std::max(1, std::min(tuning.ploc_radius, kPlocMaxRadius));
+    uint32_t c = (uint32_t)n, node_base = 0;
+    int cur = 0;
+    while (c > 1) {
+      const int gc = grid_for((int64_t)c, block, 256 * 8);
+      hipLaunchKernelGGL(k_ploc_nearest, dim3(gc), dim3(kPlocBlock), 0, st, c, radius, cl_box[cur], d_nn);
+      hipLaunchKernelGGL(k_ploc_flags, dim3(gc), dim3(block), 0, st, c, d_nn, d_pflags);
+      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_pscan_tmp, pscan_bytes, d_pflags, d_pscan, (int)c, st));
+      hipLaunchKernelGGL(k_ploc_merge, dim3(gc), dim3(block), 0, st, c, node_base, d_nn, d_pflags, d_pscan, cl_ref[cur], cl_box[cur], cl_ref[cur ^ 1],
+                         cl_box[cur ^ 1], t, d_counts);
+      uint32_t left = 0;
+      HIP_TRY(hipMemcpyAsync(&left, d_counts, sizeof left, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (left == 0 || left >= c) return fail(RT_ERR_HIP, "the clustering pass of the device build merged nothing");
+      node_base += c - left;  // every pair takes one cluster away and adds one node
+      c = left;
+      cur ^= 1;
+      ploc_iterations++;
+    }
+    if (node_base != (uint32_t)n_internal) return fail(RT_ERR_HIP, "the clustering pass of the device build lost a node");
+    root_node = (uint32_t)n_internal - 1u;  // the last pair merged
+    HIP_TRY(hipMemcpyAsync(&tree_height, t.height + root_node, sizeof tree_height, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_leaf_ranks, dim3(grid), dim3(block), 0, st, n, t, d_rank);
+    HIP_TRY(hipStreamSynchronize(st));
   } else {
-    if ((rc = dev_alloc(h, &o_nodes_q, (size_t)n_internal)) != RT_OK) return rc;
-    const int gi = grid_for(n_internal, block, 256 * 8);
-    hipLaunchKernelGGL(k_karras, dim3(gi), dim3(block), 0, st, n, keys, d_child_l, d_child_r);
+    if (!topdown) hipLaunchKernelGGL(k_karras, dim3(gi), dim3(block), 0, st, n, keys, d_child_l, d_child_r);
     HIP_TRY(hipMemsetAsync(d_height[0], 0xff, (size_t)n_internal * sizeof(int32_t), st));
     int cur = 0, passes = 0;
     int32_t root_height = -1;
@@ -494,11 +747,21 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
       if (passes > 4096) return fail(RT_ERR_HIP, "the bottom-up pass of the device build does not terminate");
     }
     tree_height = root_height;
-    if (tree_height > kMaxStackDepth)
-      return fail(RT_ERR_UNSUPPORTED, "the device-built BVH is " + std::to_string(tree_height) + " levels deep (limit 64): use the host build for this scene");
+  }
+  if (tree_height > kMaxStackDepth)
+    return fail(RT_ERR_UNSUPPORTED, "the device-built BVH is " + std::to_string(tree_height) + " levels deep (limit 64): use the host build for this scene");
+  // ---- the records the kernels read
+  hipLaunchKernelGGL(k_emit_prims, dim3(grid), dim3(block), 0, st, n, ids, d_tri_pos, d_slot, d_elements, d_tris, d_quads, d_spheres, o_tris, tri_stride,
+                     o_shade, o_quads, o_spheres, d_leaf_ref, d_rank);
+  if (n_internal == 0) {
+    HIP_TRY(hipMemcpyAsync(&root_ref, d_leaf_ref, sizeof root_ref, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemset(o_nodes, 0, sizeof(DevNode)));
+  } else {
+    if ((rc = dev_alloc(h, &o_nodes_q, (size_t)n_internal)) != RT_OK) return rc;
     hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(block), 0, st, n_internal, d_child_l, d_child_r, ids, d_leaf_ref, d_boxes, d_node_boxes, gridc, o_nodes,
                        o_nodes_q, d_sums);
-    root_ref = 0;
+    root_ref = root_node;
   }
   double sums[2] = {0.0, 0.0};
   HIP_TRY(hipMemcpyAsync(sums, d_sums, sizeof sums, hipMemcpyDeviceToHost, st));
@@ -565,7 +828,11 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   if ((rc = noalloc_warm_up(h)) != RT_OK) return rc;
   if (verbose) {
     auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "rt_hip build: %d elements, height %d, copies in %.1f ms, build %.1f ms, grid %s (boxes %.1f %% larger)\n", n, tree_height,
+    fprintf(stderr, "rt_hip build: %d elements, %s, height %d, copies in %.1f ms, build %.1f ms, grid %s (boxes %.1f %% larger)\n", n,
+            ploc ? ("clustered in " + std::to_string(ploc_iterations) + " iterations").c_str()
+            : topdown ? ((method == 2 ? "the reference's bucketed top-down build, " : "the reference's midpoint top-down build, ") + std::to_string(td_levels) + " levels").c_str()
+                      : "radix tree",
+            tree_height,
             std::chrono::duration<double, std::milli>(t_upload - lap_t0).count(), std::chrono::duration<double, std::milli>(now - t_upload).count(),
             use_grid ? "on" : "off", sums[1] > 0 ? 100.0 * (sums[0] / sums[1] - 1.0) : 0.0);
   }

@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--max-batches", type=int, default=64)
     ap.add_argument("--soup", action="store_true", help="the triangle soup of BASELINE's largest configuration instead of the mesh (batches of 16, up to 4)")
     ap.add_argument("--no-count", action="store_true", help="time the production kernels (the visit-counting ones run at four waves per SIMD)")
+    ap.add_argument("--split", default="SAH", help="the host build's bvh_split_method (SAH or Mid)")
+    ap.add_argument("--only-device", action="store_true", help="skip the host-built tree's renders")
+    ap.add_argument("--reupload", action="store_true", help="also: the device-built tree downloaded and uploaded again like a host-built one (tree shape apart from record layout)")
     args = ap.parse_args()
     from raytracer_amd import RenderIntegrator, abi, scenes
     from raytracer_amd.integrator import ResidentScene
@@ -30,7 +33,14 @@ def main():
         scene_path, config_path = scenes.materialize_soup(d, args.triangles, args.size, args.size * 9 // 16, batch=16, max_batches=4, min_batches=2)
     else:
         scene_path, config_path = scenes.materialize_c3(d, args.triangles, args.size, args.size, batch=16, max_batches=args.max_batches, min_batches=2)
-    out = {"triangles": args.triangles, "image": [args.size, args.size]}
+    if args.split != "SAH":
+        with open(config_path) as f:
+            cj = json.load(f)
+        cj["bvh_split_method"] = args.split
+        config_path = config_path.replace(".json", f"_{args.split}.json")
+        with open(config_path, "w") as f:
+            json.dump(cj, f)
+    out = {"triangles": args.triangles, "image": [args.size, args.size], "host_split": args.split}
     # host path: load + expand + reference-order SAH build, upload, render
     t0 = time.perf_counter()
     ri = RenderIntegrator.new_from_json(scene_path, config_path).prepare()
@@ -39,9 +49,10 @@ def main():
     t2 = time.perf_counter()
     cfg = ri.config.copy()
     cfg.flags = abi.RT_FLAG_TIME_KERNELS | (0 if args.no_count else abi.RT_FLAG_COUNT_VISITS)
-    host.render(cfg)  # first render pays for the working memory
+    if not args.only_device:
+        host.render(cfg)  # first render pays for the working memory
     t3 = time.perf_counter()
-    _, st = host.render(cfg)
+    _, st = host.render(cfg) if not args.only_device else (None, abi.RtStats())
     t4 = time.perf_counter()
     out["host_tree"] = {"load_expand_build_s": t1 - t0, "upload_s": t2 - t1, "first_render_s": t3 - t2, "render_s": t4 - t3,
                         "mrays_per_s": st.rays / (t4 - t3) / 1e6, "extend_ms": st.trace_kernel_ms, "shade_ms": st.shade_kernel_ms,
@@ -61,6 +72,49 @@ def main():
                           "extend_ms": sd.trace_kernel_ms, "shade_ms": sd.shade_kernel_ms,
                           "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1),
                           "stack_block_moves_per_ray": sd.stack_block_moves / max(sd.rays_traced, 1), "bvh_depth": dev.bvh_depth() if hasattr(dev, "bvh_depth") else None}
+    if args.reupload:
+        import ctypes as C
+        import numpy as np
+        raw = dev.download_tree()
+        dt = np.dtype([("is_leaf", "<i4"), ("element", "<i4"), ("l", "<i4"), ("r", "<i4"), ("boxes", "<f8", (12,))])
+        a = np.frombuffer(raw, dtype=dt).copy()
+        # the upload wants children after their parents: relabel in preorder
+        left, right, leaf = a["l"].tolist(), a["r"].tolist(), a["is_leaf"].tolist()
+        order, stack = [], [0]
+        while stack:
+            i = stack.pop()
+            order.append(i)
+            if not leaf[i]:
+                stack.append(right[i])
+                stack.append(left[i])
+        order = np.array(order, dtype=np.int64)
+        rank = np.empty(len(a), dtype=np.int32)
+        rank[order] = np.arange(len(a), dtype=np.int32)
+        b = a[order]
+        inner = b["is_leaf"] == 0
+        b["l"][inner] = rank[b["l"][inner]]
+        b["r"][inner] = rank[b["r"][inner]]
+        nodes = (abi.RtNode * len(b)).from_buffer_copy(b.tobytes())
+        twin = abi.RtScene()
+        C.memmove(C.byref(twin), ri.scene, C.sizeof(abi.RtScene))
+        twin.nodes = C.cast(nodes, C.POINTER(abi.RtNode))
+        twin.n_nodes = len(nodes)
+        t9 = time.perf_counter()
+        re_up = ResidentScene(C.pointer(twin), 0)
+        t10 = time.perf_counter()
+        re_up.render(cfg)
+        t11 = time.perf_counter()
+        _, sr = re_up.render(cfg)
+        t12 = time.perf_counter()
+        out["device_tree_uploaded_by_the_host_path"] = {"upload_s": t10 - t9, "render_s": t12 - t11, "extend_ms": sr.trace_kernel_ms, "shade_ms": sr.shade_kernel_ms,
+                                                        "node_visits_per_ray": sr.node_visits / max(sr.rays_traced, 1), "leaf_tests_per_ray": sr.leaf_tests / max(sr.rays_traced, 1)}
+        re_up.close()
+    def waves(x):
+        return {"wave_node_steps_per_ray": x.wave_node_steps / max(x.rays_traced, 1), "wave_leaf_steps_per_ray": x.wave_leaf_steps / max(x.rays_traced, 1),
+                "node_lane_share": x.node_visits / max(64 * x.wave_node_steps, 1), "leaf_lane_share": x.leaf_tests / max(64 * x.wave_leaf_steps, 1),
+                "cycles_refill_node_leaf": [int(x.wave_cycles_refill), int(x.wave_cycles_node), int(x.wave_cycles_leaf)]}
+    out["host_tree"].update(waves(st))
+    out["device_tree"].update(waves(sd))
     out["note"] = "load_expand_build_s includes OBJ parsing and element expansion, which the device path needs too (it starts from the expanded primitives)"
     print(json.dumps(out))
 
