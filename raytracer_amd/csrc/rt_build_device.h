@@ -557,23 +557,29 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   } else {
     // ---- the reference's top-down build, one level of the tree per trip
     const int sah = method == 2 ? 1 : 0;
+    const uint32_t chunks = ((uint32_t)n + 63u) / 64u, n_items = 2u * chunks;
     Rec64 *d_recs;
-    uint32_t *d_seg_of[2], *d_class_key, *d_n_left, *d_new_count, *d_base, *d_counts;
+    uint32_t *d_seg_of[2], *d_class_key, *d_n_left, *d_new_count, *d_base, *d_counts, *d_item_key;
     uint8_t *d_bins;
-    Cnt16 *d_before;
-    Box12 *d_class_box;
+    Cnt16 *d_item_cnt, *d_carry_cnt, *d_seg_total;
+    Box12 *d_class_box, *d_item_box, *d_carry_box;
     double *d_child_cb;
     TdSegments sg[2];
     HIP_TRY(tmp.alloc(&d_recs, (size_t)n));
     HIP_TRY(tmp.alloc(&d_bins, (size_t)n));
-    HIP_TRY(tmp.alloc(&d_before, (size_t)n));
     HIP_TRY(tmp.alloc(&d_class_box, (size_t)n));
     HIP_TRY(tmp.alloc(&d_class_key, (size_t)n));
+    HIP_TRY(tmp.alloc(&d_seg_total, (size_t)n));
     HIP_TRY(tmp.alloc(&d_n_left, (size_t)n));
     HIP_TRY(tmp.alloc(&d_new_count, (size_t)n));
     HIP_TRY(tmp.alloc(&d_base, (size_t)n));
     HIP_TRY(tmp.alloc(&d_child_cb, 12 * (size_t)n));
     HIP_TRY(tmp.alloc(&d_counts, 4));
+    HIP_TRY(tmp.alloc(&d_item_key, (size_t)n_items));
+    HIP_TRY(tmp.alloc(&d_item_cnt, (size_t)n_items));
+    HIP_TRY(tmp.alloc(&d_carry_cnt, (size_t)n_items));
+    HIP_TRY(tmp.alloc(&d_item_box, (size_t)n_items));
+    HIP_TRY(tmp.alloc(&d_carry_box, (size_t)n_items));
     for (int k = 0; k < 2; k++) {
       HIP_TRY(tmp.alloc(&d_seg_of[k], (size_t)n));
       HIP_TRY(tmp.alloc(&sg[k].lo, (size_t)n));
@@ -583,34 +589,36 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
       HIP_TRY(tmp.alloc(&sg[k].cb, 6 * (size_t)n));
     }
     const TdTree tree{d_child_l, d_child_r};
-    rocprim::transform_iterator<const uint8_t *, OneHot16, Cnt16> one_hot(d_bins, OneHot16());
+    Cnt16 zero_cnt;
+    for (int k = 0; k < kTdBuckets; k++) zero_cnt.c[k] = 0u;
+    Box12 no_box;
+    for (int k = 0; k < 3; k++) no_box.bmn[k] = no_box.cmn[k] = INFINITY, no_box.bmx[k] = no_box.cmx[k] = -INFINITY;
     size_t b1 = 0, b2 = 0, b3 = 0;
-    {
-      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> probe(d_ids[0], RecBox12{d_recs});
-      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, b1, d_seg_of[0], one_hot, d_before, Cnt16Sum(), n, hipcub::Equality(), st));
-      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, b2, d_class_key, probe, d_class_box, Box12Union(), n, hipcub::Equality(), st));
-      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b3, d_new_count, d_base, n, st));
-    }
+    HIP_TRY(hipcub::DeviceScan::ExclusiveScanByKey(nullptr, b1, d_item_key, d_item_cnt, d_carry_cnt, Cnt16Sum(), zero_cnt, n_items, hipcub::Equality(), st));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveScanByKey(nullptr, b2, d_item_key, d_item_box, d_carry_box, Box12Union(), no_box, n_items, hipcub::Equality(), st));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b3, d_new_count, d_base, n, st));
     char *d_td_tmp;
     HIP_TRY(tmp.alloc(&d_td_tmp, std::max(b1, std::max(b2, b3))));
+    const int gw = grid_for((int64_t)chunks, kTdWavesPerBlock, 256 * 8);  // one wave per 64 positions
     int cur = 0;  // d_ids[cur], d_seg_of[cur], sg[cur] describe the level about to be split
     hipLaunchKernelGGL(k_td_element_recs, dim3(grid), dim3(block), 0, st, n, d_elements, d_tris, d_quads, d_spheres, d_recs, d_ids[0], d_seg_of[0]);
-    HIP_TRY(hipMemsetAsync(d_class_key, 0, (size_t)n * sizeof(uint32_t), st));
-    {
-      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> boxes_of(d_ids[0], RecBox12{d_recs});
-      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b2, d_class_key, boxes_of, d_class_box, Box12Union(), n, hipcub::Equality(), st));
-    }
-    hipLaunchKernelGGL(k_td_root, dim3(1), dim3(64), 0, st, n, d_class_box, sg[0], tree);
+    HIP_TRY(hipMemsetAsync(d_class_key, 0, (size_t)n * sizeof(uint32_t), st));  // every element in one class: the root's boxes
+    hipLaunchKernelGGL(k_td_class_boxes, dim3(gw), dim3(block), 0, st, n, d_ids[0], d_class_key, d_recs, d_class_box, d_item_key, d_item_box);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveScanByKey(d_td_tmp, b2, d_item_key, d_item_box, d_carry_box, Box12Union(), no_box, n_items, hipcub::Equality(), st));
+    hipLaunchKernelGGL(k_td_root, dim3(1), dim3(64), 0, st, n, d_class_box, d_carry_box, sg[0], tree);
     uint32_t n_seg = 1, n_active = n >= 3 ? 1u : 0u;
     while (n_active > 0) {
       if (++td_levels > 4 * kMaxStackDepth) return fail(RT_ERR_UNSUPPORTED, "the top-down device build does not terminate: use the host build for this scene");
       const int gs = grid_for((int64_t)n_seg, block, 256 * 8);
-      hipLaunchKernelGGL(k_td_bins, dim3(grid), dim3(block), 0, st, n, sah, d_ids[cur], d_seg_of[cur], sg[cur], d_recs, d_bins, d_bad);
-      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b1, d_seg_of[cur], one_hot, d_before, Cnt16Sum(), n, hipcub::Equality(), st));
-      hipLaunchKernelGGL(k_td_scatter, dim3(grid), dim3(block), 0, st, n, d_ids[cur], d_seg_of[cur], sg[cur], d_bins, d_before, d_ids[cur ^ 1], d_class_key);
-      rocprim::transform_iterator<const uint32_t *, RecBox12, Box12> boxes_of(d_ids[cur ^ 1], RecBox12{d_recs});
-      HIP_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_td_tmp, b2, d_class_key, boxes_of, d_class_box, Box12Union(), n, hipcub::Equality(), st));
-      hipLaunchKernelGGL(k_td_split, dim3(gs), dim3(block), 0, st, n_seg, sah, sg[cur], d_before, d_class_box, tree, d_n_left, d_child_cb, d_new_count, d_bad);
+      hipLaunchKernelGGL(k_td_count, dim3(gw), dim3(block), 0, st, n, sah, d_ids[cur], d_seg_of[cur], sg[cur], d_recs, d_bins, d_item_key, d_item_cnt, d_bad);
+      HIP_TRY(hipcub::DeviceScan::ExclusiveScanByKey(d_td_tmp, b1, d_item_key, d_item_cnt, d_carry_cnt, Cnt16Sum(), zero_cnt, n_items, hipcub::Equality(), st));
+      hipLaunchKernelGGL(k_td_totals, dim3(gw), dim3(block), 0, st, n, d_seg_of[cur], sg[cur], d_bins, d_carry_cnt, d_seg_total);
+      hipLaunchKernelGGL(k_td_scatter, dim3(gw), dim3(block), 0, st, n, d_ids[cur], d_seg_of[cur], sg[cur], d_bins, d_carry_cnt, d_seg_total, d_ids[cur ^ 1],
+                         d_class_key);
+      hipLaunchKernelGGL(k_td_class_boxes, dim3(gw), dim3(block), 0, st, n, d_ids[cur ^ 1], d_class_key, d_recs, d_class_box, d_item_key, d_item_box);
+      HIP_TRY(hipcub::DeviceScan::ExclusiveScanByKey(d_td_tmp, b2, d_item_key, d_item_box, d_carry_box, Box12Union(), no_box, n_items, hipcub::Equality(), st));
+      hipLaunchKernelGGL(k_td_split, dim3(gs), dim3(block), 0, st, n_seg, sah, sg[cur], d_seg_total, d_class_box, d_carry_box, tree, d_n_left, d_child_cb,
+                         d_new_count, d_bad);
       HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_td_tmp, b3, d_new_count, d_base, (int)n_seg, st));
       HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint32_t), st));
       hipLaunchKernelGGL(k_td_segments, dim3(gs), dim3(block), 0, st, n_seg, sg[cur], d_n_left, d_child_cb, d_base, sg[cur ^ 1], d_counts);

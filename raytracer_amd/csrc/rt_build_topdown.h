@@ -4,14 +4,16 @@
 // children from the concatenated buckets -- in which the children of a node depend on nothing but the node's own element
 // list.  All nodes of one depth are therefore split together, one LEVEL per trip of a host loop:
 //
-//   k_td_bins      the bucket of every element of every node of the level (one lane per element)
-//   scan by key    per node, how many elements of each bucket precede each element (sixteen counters per element)
-//   k_td_scatter   the stable counting sort of every node's range by bucket = the concatenation of the reference's
-//                  per-bucket vectors (:68-74), so the element order inside a child is the reference's
-//   scan by key    per (node, bucket), the union of the element boxes and of their centroids
-//   k_td_split     per node: bucket areas, the fifteen plane costs summed in the reference's order, the first cheapest
-//                  plane, the two children (leaves, two-element nodes, or ranges for the next level)
-//   k_td_segments  the next level's table of ranges
+//   k_td_count        the bucket of every element of every node of the level; per 64 positions, elements per bucket
+//   k_td_totals       per node, its elements per bucket
+//   k_td_scatter      the stable counting sort of every node's range by bucket = the concatenation of the reference's
+//                     per-bucket vectors (:68-74), so the element order inside a child is the reference's
+//   k_td_class_boxes  per (node, bucket), the union of the element boxes and of their centroids
+//   k_td_split        per node: bucket areas, the fifteen plane costs summed in the reference's order, the first cheapest
+//                     plane, the two children (leaves, two-element nodes, or ranges for the next level)
+//   k_td_segments     the next level's table of ranges
+// (the element passes are wave-wide ballots and shuffles over 64 positions each; what crosses those chunks goes through
+// two small items per chunk and a library scan by key over the items)
 //
 // A subtree over c elements has c - 1 internal nodes, so a node's place in the reference's preorder is known when its
 // parent splits: left child right after the parent, right child n_left places after it.  The leaves come out in the
@@ -138,50 +140,189 @@ RT_DEV TdPlan td_plan(const double *cb, bool sah) {
   return p;
 }
 
-__global__ void __launch_bounds__(256) k_td_bins(int32_t n, int sah, const uint32_t *idx, const uint32_t *seg_of, TdSegments sg, const Rec64 *recs,
-                                                  uint8_t *bins, uint32_t *error) {
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t s = seg_of[i];
+// ---- per level, the element passes.  One wave takes 64 consecutive positions (a "chunk").  Ranges are runs of positions, so
+// the lanes of one range form a run of lanes; what a range needs from beyond the chunk arrives through two items per chunk --
+// one for the run its first lane is in, one for the run its last lane is in (a chunk inside one range: the first item holds
+// everything, the second nothing) -- and an exclusive scan by key over those items (64 times fewer than elements).
+RT_DEV uint32_t td_bin_of(const TdSegments &sg, uint32_t s, uint32_t p, int sah, const Rec64 *recs, const uint32_t *idx, uint32_t *error) {
+  const TdPlan plan = td_plan(sg.cb + 6 * (size_t)s, sah != 0);
+  if (plan.halves) return p - sg.lo[s] < sg.cnt[s] / 2u ? 0u : 1u;
+  const double c = recs[idx[p]].c[plan.axis];
+  if (!sah) return c < plan.splitpoint ? 0u : 1u;  // :366-381
+  const double b = plan.k1 * (c - plan.k0);
+  // `as usize`: truncation, saturating, NaN -> 0
+  uint32_t bin = (b != b || b <= 0.0) ? 0u : (b >= 4e9 ? 0xffffffffu : (uint32_t)b);
+  if (bin >= (uint32_t)kTdBuckets) {
+    atomicOr(error, 1u);
+    bin = kTdBuckets - 1;
+  }
+  return bin;
+}
+struct TdChunk {  // what every lane of a wave knows about its chunk
+  uint32_t p, s, s_first, s_last, n_valid;
+  bool valid, act;
+  unsigned long long head, tail;  // lanes of the first / the last run
+  int run_start;                  // first lane of this lane's run
+};
+RT_DEV TdChunk td_chunk(uint32_t chunk, int32_t n, const uint32_t *seg_of, const TdSegments &sg) {
+  TdChunk c;
+  const uint32_t lane = threadIdx.x & 63u;
+  c.p = chunk * 64u + lane;
+  c.valid = c.p < (uint32_t)n;
+  c.s = c.valid ? seg_of[c.p] : 0xffffffffu;
+  c.act = c.valid && sg.active[c.s] != 0u;
+  c.n_valid = min(64u, (uint32_t)n - chunk * 64u);
+  c.s_first = (uint32_t)__shfl((int)c.s, 0);
+  c.s_last = (uint32_t)__shfl((int)c.s, (int)c.n_valid - 1);
+  c.head = __ballot(c.valid && c.s == c.s_first);
+  c.tail = __ballot(c.valid && c.s == c.s_last);
+  const uint32_t s_prev = (uint32_t)__shfl_up((int)c.s, 1);
+  const unsigned long long starts = __ballot(lane == 0u || c.s != s_prev);
+  c.run_start = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+  return c;
+}
+constexpr int kTdWavesPerBlock = 4;
+RT_DEV uint32_t td_wave() { return blockIdx.x * kTdWavesPerBlock + (threadIdx.x >> 6); }
+
+// The bucket of every element (kept in `bins`), and the chunk's two items: elements per bucket in its first and in its last run.
+__global__ void __launch_bounds__(256) k_td_count(int32_t n, int sah, const uint32_t *idx, const uint32_t *seg_of, TdSegments sg, const Rec64 *recs,
+                                                   uint8_t *bins, uint32_t *item_key, Cnt16 *item_val, uint32_t *error) {
+  const uint32_t lane = threadIdx.x & 63u, chunks = ((uint32_t)n + 63u) / 64u;
+  for (uint32_t chunk = td_wave(); chunk < chunks; chunk += gridDim.x * kTdWavesPerBlock) {
+    const TdChunk c = td_chunk(chunk, n, seg_of, sg);
     uint32_t bin = 0;
-    if (sg.active[s]) {
-      const TdPlan p = td_plan(sg.cb + 6 * (size_t)s, sah != 0);
-      if (p.halves) {
-        bin = (uint32_t)i - sg.lo[s] < sg.cnt[s] / 2u ? 0u : 1u;
-      } else if (sah) {
-        const double b = p.k1 * (recs[idx[i]].c[p.axis] - p.k0);
-        // `as usize`: truncation, saturating, NaN -> 0
-        bin = (b != b || b <= 0.0) ? 0u : (b >= 4e9 ? 0xffffffffu : (uint32_t)b);
-        if (bin >= (uint32_t)kTdBuckets) {
-          atomicOr(error, 1u);
-          bin = kTdBuckets - 1;
-        }
-      } else {
-        bin = recs[idx[i]].c[p.axis] < p.splitpoint ? 0u : 1u;  // :366-381
-      }
+    if (c.act) bin = td_bin_of(sg, c.s, c.p, sah, recs, idx, error);
+    if (c.valid) bins[c.p] = (uint8_t)bin;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kTdBuckets; b++) {
+      const unsigned long long m = __ballot(c.act && bin == b);
+      if (lane == b) mine = m;
     }
-    bins[i] = (uint8_t)bin;
+    const bool single = c.s_first == c.s_last;
+    if (lane < (uint32_t)kTdBuckets) {
+      item_val[2 * (size_t)chunk].c[lane] = (uint32_t)__popcll(mine & c.head);
+      item_val[2 * (size_t)chunk + 1].c[lane] = single ? 0u : (uint32_t)__popcll(mine & c.tail);
+    }
+    if (lane == 0u) {
+      item_key[2 * (size_t)chunk] = c.s_first;
+      item_key[2 * (size_t)chunk + 1] = c.s_last;
+    }
   }
 }
 
-// `before[i]` = inclusive counts per bucket over the positions lo..i of i's range.  Writes the element to its place in the
-// stable order by bucket and gives every (range, bucket) class a key of its own: the position at which it starts.
+// `carry[2 * chunk]` = elements per bucket of the chunk's first run's range in earlier chunks.  The lane that holds the last
+// element of an active range adds up the range's elements per bucket.
+__global__ void __launch_bounds__(256) k_td_totals(int32_t n, const uint32_t *seg_of, TdSegments sg, const uint8_t *bins, const Cnt16 *carry,
+                                                    Cnt16 *seg_total) {
+  const uint32_t lane = threadIdx.x & 63u, chunks = ((uint32_t)n + 63u) / 64u;
+  for (uint32_t chunk = td_wave(); chunk < chunks; chunk += gridDim.x * kTdWavesPerBlock) {
+    const TdChunk c = td_chunk(chunk, n, seg_of, sg);
+    const uint32_t bin = c.valid ? bins[c.p] : 0u;
+    const bool closes = c.act && c.p == sg.lo[c.s] + sg.cnt[c.s] - 1u;
+    const unsigned long long run = ((2ull << lane) - 1ull) & ~((1ull << c.run_start) - 1ull);  // lanes run_start..lane
+    Cnt16 t;
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kTdBuckets; b++) t.c[b] = (uint32_t)__popcll(__ballot(c.act && bin == b) & run);
+    if (closes) {
+      if (c.s == c.s_first) {
+        const Cnt16 &in = carry[2 * (size_t)chunk];
+#pragma unroll
+        for (int b = 0; b < kTdBuckets; b++) t.c[b] += in.c[b];
+      }
+      seg_total[c.s] = t;
+    }
+  }
+}
+
+// The stable counting sort of every active range by bucket: the element's new place = start of its bucket's class + elements of
+// the class before it (in earlier chunks: the carry; in this chunk: the lanes before it).  Every class gets a key of its own,
+// the position at which it starts; the elements of the other ranges stay and carry no key.
+constexpr uint32_t kTdNoClass = 0xffffffffu;
 __global__ void __launch_bounds__(256) k_td_scatter(int32_t n, const uint32_t *idx, const uint32_t *seg_of, TdSegments sg, const uint8_t *bins,
-                                                     const Cnt16 *before, uint32_t *idx_out, uint32_t *class_key) {
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t s = seg_of[i];
-    if (!sg.active[s]) {
-      idx_out[i] = idx[i];
-      class_key[i] = (uint32_t)i;
+                                                     const Cnt16 *carry, const Cnt16 *seg_total, uint32_t *idx_out, uint32_t *class_key) {
+  const uint32_t lane = threadIdx.x & 63u, chunks = ((uint32_t)n + 63u) / 64u;
+  for (uint32_t chunk = td_wave(); chunk < chunks; chunk += gridDim.x * kTdWavesPerBlock) {
+    const TdChunk c = td_chunk(chunk, n, seg_of, sg);
+    const uint32_t bin = c.valid ? bins[c.p] : 0u;
+    unsigned long long same = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kTdBuckets; b++) {
+      const unsigned long long m = __ballot(c.act && bin == b);
+      if (bin == b) same = m;
+    }
+    if (!c.valid) continue;
+    if (!c.act) {
+      idx_out[c.p] = idx[c.p];
+      class_key[c.p] = kTdNoClass;
       continue;
     }
-    const uint32_t lo = sg.lo[s], b = bins[i];
-    const Cnt16 &total = before[lo + sg.cnt[s] - 1u];
-    uint32_t start = lo;
-    for (uint32_t k = 0; k < b; k++) start += total.c[k];
-    const uint32_t dest = start + before[i].c[b] - 1u;
-    idx_out[dest] = idx[i];
+    const unsigned long long before = ((1ull << lane) - 1ull) & ~((1ull << c.run_start) - 1ull);  // lanes run_start..lane-1
+    const Cnt16 &total = seg_total[c.s];
+    uint32_t start = sg.lo[c.s];
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)kTdBuckets; b++) start += b < bin ? total.c[b] : 0u;
+    uint32_t dest = start + (uint32_t)__popcll(same & before);
+    if (c.s == c.s_first) dest += carry[2 * (size_t)chunk].c[bin];
+    idx_out[dest] = idx[c.p];
     class_key[dest] = start;
   }
+}
+
+RT_DEV Box12 box12_identity() {
+  Box12 b;
+  for (int k = 0; k < 3; k++) b.bmn[k] = b.cmn[k] = INFINITY, b.bmx[k] = b.cmx[k] = -INFINITY;
+  return b;
+}
+RT_DEV Box12 box12_shfl_up(const Box12 &b, int d) {
+  Box12 r;
+  for (int k = 0; k < 3; k++) {
+    r.bmn[k] = __shfl_up(b.bmn[k], d);
+    r.bmx[k] = __shfl_up(b.bmx[k], d);
+    r.cmn[k] = __shfl_up(b.cmn[k], d);
+    r.cmx[k] = __shfl_up(b.cmx[k], d);
+  }
+  return r;
+}
+// After the sort a class is a run of positions.  class_box[p], written by the last lane of every run of a chunk = the union
+// over the run's lanes; the chunk's two items = the unions over its first and over its last run.  A class that began in an
+// earlier chunk is completed by the reader: class_box[its last position] united with carry[2 * that position's chunk].
+__global__ void __launch_bounds__(256) k_td_class_boxes(int32_t n, const uint32_t *idx, const uint32_t *class_key, const Rec64 *recs, Box12 *class_box,
+                                                         uint32_t *item_key, Box12 *item_box) {
+  const uint32_t lane = threadIdx.x & 63u, chunks = ((uint32_t)n + 63u) / 64u;
+  for (uint32_t chunk = td_wave(); chunk < chunks; chunk += gridDim.x * kTdWavesPerBlock) {
+    const uint32_t p = chunk * 64u + lane, n_valid = min(64u, (uint32_t)n - chunk * 64u);
+    const bool valid = p < (uint32_t)n;
+    const uint32_t key = valid ? class_key[p] : kTdNoClass;
+    const bool live = key != kTdNoClass;
+    Box12 box = box12_identity();
+    if (live) box = RecBox12{recs}(idx[p]);
+    const uint32_t key_prev = (uint32_t)__shfl_up((int)key, 1), key_next = (uint32_t)__shfl_down((int)key, 1);
+    const unsigned long long starts = __ballot(lane == 0u || key != key_prev);
+    const int run_start = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+#pragma unroll
+    for (int d = 1; d < 64; d *= 2) {
+      const Box12 other = box12_shfl_up(box, d);
+      if ((int)lane - d >= run_start) box = Box12Union()(box, other);
+    }
+    const bool run_last = lane == n_valid - 1u || key != key_next;
+    if (live && run_last) class_box[p] = box;
+    const uint32_t key_first = (uint32_t)__shfl((int)key, 0), key_last = (uint32_t)__shfl((int)key, (int)n_valid - 1);
+    const uint32_t head_last = (uint32_t)__popcll(__ballot(valid && key == key_first && run_start == 0)) - 1u;
+    if (lane == head_last) {
+      item_key[2 * (size_t)chunk] = key_first;
+      item_box[2 * (size_t)chunk] = box;
+    }
+    if (lane == n_valid - 1u) {
+      item_key[2 * (size_t)chunk + 1] = key_last;
+      item_box[2 * (size_t)chunk + 1] = run_start == 0 ? box12_identity() : box;  // one run over the whole chunk: the first item holds it
+    }
+  }
+}
+RT_DEV Box12 td_class_total(const Box12 *class_box, const Box12 *carry, uint32_t start, uint32_t last) {
+  Box12 b = class_box[last];
+  if (start < (last & ~63u)) b = Box12Union()(b, carry[2 * (size_t)(last >> 6)]);
+  return b;
 }
 
 struct TdTree {
@@ -196,10 +337,11 @@ RT_DEV uint32_t td_child(const TdTree &t, uint32_t lo, uint32_t cnt, uint32_t no
   return node;
 }
 
-// Buckets::split_objects (bvh_node_sah.rs:28-79) for every active range; `class_box[p]` = union over the positions of p's
-// class up to p (so a class's last position holds the class's boxes).  Per range: n_left, and the children's centroid boxes.
-__global__ void __launch_bounds__(256) k_td_split(uint32_t n_seg, int sah, TdSegments sg, const Cnt16 *before, const Box12 *class_box, TdTree tree,
-                                                   uint32_t *n_left_out, double *child_cb, uint32_t *new_count, uint32_t *error) {
+// Buckets::split_objects (bvh_node_sah.rs:28-79) for every active range, from its elements per bucket (seg_total) and its
+// classes' boxes (td_class_total).  Per range: n_left, and the children's centroid boxes.
+__global__ void __launch_bounds__(256) k_td_split(uint32_t n_seg, int sah, TdSegments sg, const Cnt16 *seg_total, const Box12 *class_box,
+                                                   const Box12 *carry_box, TdTree tree, uint32_t *n_left_out, double *child_cb, uint32_t *new_count,
+                                                   uint32_t *error) {
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seg; s += gridDim.x * blockDim.x) {
     if (!sg.active[s]) {
       new_count[s] = 1u;
@@ -208,7 +350,7 @@ __global__ void __launch_bounds__(256) k_td_split(uint32_t n_seg, int sah, TdSeg
     }
     const uint32_t lo = sg.lo[s], cnt = sg.cnt[s], node = sg.node[s];
     const TdPlan p = td_plan(sg.cb + 6 * (size_t)s, sah != 0);
-    const Cnt16 total = before[lo + cnt - 1u];
+    const Cnt16 total = seg_total[s];
     double area[kTdBuckets];
     uint32_t end = lo;
     uint32_t last[kTdBuckets];
@@ -218,7 +360,7 @@ __global__ void __launch_bounds__(256) k_td_split(uint32_t n_seg, int sah, TdSeg
       if (i < p.n_bins && total.c[i]) {
         end += total.c[i];
         last[i] = end - 1u;
-        const Box12 &b = class_box[last[i]];
+        const Box12 b = td_class_total(class_box, carry_box, end - total.c[i], last[i]);
         const double x = b.bmx[0] - b.bmn[0], y = b.bmx[1] - b.bmn[1], z = b.bmx[2] - b.bmn[2];
         area[i] = x * y + y * z + z * x;  // aabb.rs:115-119
       }
@@ -250,7 +392,7 @@ __global__ void __launch_bounds__(256) k_td_split(uint32_t n_seg, int sah, TdSeg
     double lcb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, rcb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int i = 0; i < p.n_bins; i++) {
       if (!total.c[i]) continue;
-      const Box12 &b = class_box[last[i]];
+      const Box12 b = td_class_total(class_box, carry_box, last[i] + 1u - total.c[i], last[i]);
       double *cb = i < best_split ? lcb : rcb;
       if (i < best_split) n_left += total.c[i];
       for (int a = 0; a < 3; a++) cb[a] = fmin(cb[a], b.cmn[a]), cb[3 + a] = fmax(cb[3 + a], b.cmx[a]);
@@ -296,14 +438,14 @@ __global__ void __launch_bounds__(256) k_td_seg_of(int32_t n, const uint32_t *se
   }
 }
 
-// the root range: every element, node 0; its centroid box is the last entry of a scan over all elements under one key
-__global__ void k_td_root(int32_t n, const Box12 *all, TdSegments sg, TdTree tree) {
+// the root range: every element, node 0; its centroid box comes from k_td_class_boxes over all elements under one key
+__global__ void k_td_root(int32_t n, const Box12 *class_box, const Box12 *carry_box, TdSegments sg, TdTree tree) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sg.lo[0] = 0u;
     sg.cnt[0] = (uint32_t)n;
     sg.node[0] = 0u;
     sg.active[0] = n >= 3 ? 1u : 0u;
-    const Box12 &b = all[n - 1];
+    const Box12 b = td_class_total(class_box, carry_box, 0u, (uint32_t)n - 1u);
     for (int a = 0; a < 3; a++) sg.cb[a] = b.cmn[a], sg.cb[3 + a] = b.cmx[a];
     if (n == 2) td_child(tree, 0u, 2u, 0u);
   }

@@ -51,14 +51,19 @@ def ref_config(**overrides):
     return cfg
 
 
-def teapot_scene(width, height, batch, max_batches, min_batches):
+def soup_scene(n_triangles, width, height, batch, max_batches, min_batches, split="SAH"):
+    """The triangle soup of the largest configuration in small: random triangles of mixed materials in the Cornell room, a lens."""
+    return RenderIntegrator.new(scenes.scene_soup(n_triangles), scenes.config(width, height, batch, max_batches, min_batches, split=split)).prepare()
+
+
+def teapot_scene(width, height, batch, max_batches, min_batches, split="SAH"):
     """input/scene_teapot.json: teapot.obj (6 320 triangles, scaled, rotated, moved) + metal box + walls +
     quad light (attractor), with input/config.json resized."""
     import json
     with open(os.path.join(REF_INPUTS, "scene_teapot.json")) as f:
         scene = json.load(f)
     cfg = ref_config(img_width=float(width), img_height=float(height), sample_batch_size=int(batch),
-                     max_sample_batches=int(max_batches), min_sample_batches=int(min_batches))
+                     max_sample_batches=int(max_batches), min_sample_batches=int(min_batches), bvh_split_method=split)
     return RenderIntegrator.new(scene, cfg, base_dir=REF_INPUTS).prepare()
 
 

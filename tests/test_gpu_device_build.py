@@ -62,8 +62,62 @@ def _check_tree(ri, nodes):
                 assert (pts.min(0) >= np.array(mn[:])).all() and (pts.max(0) <= np.array(mx[:])).all()
 
 
+def _preorder(nodes, n_nodes):
+    """The tree as its preorder sequence (-1 for an internal node, else the leaf's element): equal sequences, equal trees."""
+    seq, stack = [], [0]
+    while stack:
+        nd = nodes[stack.pop()]
+        if nd.is_leaf:
+            seq.append(nd.element_index)
+        else:
+            seq.append(-1)
+            stack.append(nd.child_r_index)
+            stack.append(nd.child_l_index)
+    assert len(seq) == n_nodes
+    return seq
+
+
+@pytest.mark.parametrize("split", ["SAH", "Mid"])
+@pytest.mark.parametrize("which", ["c1", "knot", "teapot", "soup", "tilted", "pair"])
+def test_top_down_device_build_makes_the_hosts_tree(which, split, tmp_scene_dir, monkeypatch):
+    """The default method of rt_hip_scene_build restates BVHNode_SAH::build (bvh_node_sah.rs:256-461) level by level on the
+    device: same topology and the same depth-first leaf order as the host's restatement of the reference's recursion, for its
+    bucketed surface-area split and for its midpoint split; on trees whose boxes bound their contents therefore the same
+    hits, ids included, as the uploaded tree gives."""
+    from helpers import soup_scene
+    if which == "c1":
+        ri = c1(width=32, height=32, batch=2, split=split)
+    elif which == "knot":
+        ri = knot_scene(tmp_scene_dir, 20000, 32, 32, 2, 1, 1, split=split)
+    elif which == "teapot":
+        ri = teapot_scene(32, 32, 2, 1, 1, split=split)
+    elif which == "soup":
+        ri = soup_scene(3000, 32, 32, 2, 1, 1, split=split)
+    elif which == "tilted":
+        from test_gpu_parity import _tilted_quad_scene
+        ri = _tilted_quad_scene(split=split)
+    else:
+        ri = RenderIntegrator.new({"camera": scenes.camera(), "elements": [scenes.sphere((278, 278, 200), 120, scenes.lambertian(.5, .5, .5)),
+                                                                         scenes.sphere((100, 278, 200), 50, scenes.lambertian(.5, .5, .5))]},
+                                  scenes.config(16, 16, 2, 1, 1, split=split)).prepare()
+    monkeypatch.setenv("RT_HIP_BUILD", "2" if split == "SAH" else "3")
+    dev = ResidentScene(ri.scene, 0, build_on_device=True)
+    nodes = dev.download_tree()
+    sc = ri.scene.contents
+    assert _preorder(nodes, len(nodes)) == _preorder(sc.nodes, sc.n_nodes)
+    if which != "tilted":  # (there the uploaded tree follows the reference's visit rule, the device-built one holds true bounds)
+        host = ri.resident(0)
+        o, d = random_rays(100_000, seed=75)
+        ph, th = host.trace_rays(o, d)
+        pd, td = dev.trace_rays(o, d)
+        assert np.array_equal(th, td) and np.array_equal(ph, pd)
+    dev.close()
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
 @pytest.mark.parametrize("which", ["c1", "knot", "tilted", "single"])
-def test_device_built_tree_gives_the_oracles_hits(which, tmp_scene_dir):
+def test_device_built_tree_gives_the_oracles_hits(which, method, tmp_scene_dir, monkeypatch):
+    monkeypatch.setenv("RT_HIP_BUILD", str(method))
     if which == "c1":
         ri = c1(width=48, height=48, batch=4)
     elif which == "knot":

@@ -247,7 +247,7 @@ def test_soup_scene_with_glass_and_metal_triangles(tmp_scene_dir):
     assert abs(int(st_g.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
 
 
-def _tilted_quad_scene():
+def _tilted_quad_scene(split="SAH"):
     """A quad that is not axis-aligned: the reference boxes it by two opposite corners only
     (quad.rs:86), so parts of it stick out of its box and whether a ray finds them depends on
     the reference's irregular visit rule (bvh_node_sah.rs:215-216).  The device must follow it."""
@@ -257,7 +257,7 @@ def _tilted_quad_scene():
                                         "material": scenes.lambertian(0.6, 0.6, 0.2)}})
     sc["elements"].append({"JSONQuad": {"q": scenes._v(300, 50, 200), "u": scenes._v(150, 10, -80), "v": scenes._v(20, 200, 60),
                                         "material": scenes.metal(0.8, 0.8, 0.8, 0.0), "attractor": False}})
-    return RenderIntegrator.new(sc, scenes.config(64, 64, 4, 1, 1)).prepare()
+    return RenderIntegrator.new(sc, scenes.config(64, 64, 4, 1, 1, split=split)).prepare()
 
 
 def test_irregular_visit_rule_with_unbounded_quads():
