@@ -100,6 +100,10 @@ extern "C" {
 #define RT_MEM_HOST 0
 #define RT_MEM_DEVICE 1
 
+/* RtScene.split_method: BVHSplitMethod (bvh_node_sah.rs:11-19) */
+#define RT_SPLIT_SAH 0
+#define RT_SPLIT_MID 1
+
 /* ------------------------------------------------------------------ PODs */
 typedef struct RtVec3 {
   double x, y, z;
@@ -180,7 +184,8 @@ typedef struct RtScene {
   int32_t n_spheres;
   int32_t n_materials;
   int32_t n_attractors;
-  int32_t reserved;
+  int32_t split_method; /* RT_SPLIT_*: Config.bvh_split_method (config.rs:18), the rule the tree in `nodes` was built by;
+                           read by rt_hip_scene_build only, which builds the tree by the same rule */
   const RtNode *nodes;          /* nodes[0] is the root (bvh_node_sah.rs:164) */
   const RtElementRef *elements; /* Vec<Element> order */
   const RtTriangle *triangles;
@@ -323,18 +328,23 @@ int rt_hip_primary_hits(RtSceneHandle *handle, const RtConfig *cfg, int32_t *pri
 int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins,
                       const double *directions, int32_t *prim_id, double *t);
 
-/* Opt-in: build the BVH on the device instead of uploading the host's.  Where
- * the reference builds its tree in BVH_SAH::build (bvh_node_sah.rs:147-159,
- * 256-461: Mid or 16-bucket SAH, one host thread) this entry point takes the
- * primitives alone (scene->nodes and n_nodes are ignored) and builds a linear
- * BVH over Morton codes on the GPU; everything else is as after
- * rt_hip_scene_upload.  Differences a caller must accept:
- *   - boxes are the primitives' true bounds (the reference boxes a quad by two
- *     corners only, quad.rs:86, and can lose hits on a tilted quad's
- *     overhang; this tree finds them);
- *   - primitives hit at exactly the same t are told apart by THIS tree's
- *     depth-first leaf order, not the reference tree's.
- * Hit distances are those of the reference's primitive tests either way. */
+/* Opt-in: build the BVH on the device instead of uploading the host's.  The
+ * reference builds its tree in BVH_SAH::build (bvh_node_sah.rs:147-159,
+ * 256-461: midpoint or 16-bucket surface-area split, a recursion on one host
+ * thread).  This entry point takes the primitives alone (scene->nodes and
+ * n_nodes are ignored) and runs the same top-down build on the GPU, one level
+ * of the tree per pass, by the rule scene->split_method names: the tree has
+ * the reference's topology and the reference's depth-first leaf order
+ * (element boxes are recomputed from the primitive records, so a centroid can
+ * differ from the host's in its last bit: an element moves to another bucket
+ * only if it lies on a bucket boundary to within that bit).  Everything else
+ * is as after rt_hip_scene_upload, except that the boxes stored are the
+ * primitives' TRUE bounds: the reference boxes a quad by two corners only
+ * (quad.rs:86) and can lose hits on a tilted quad's overhang; this tree finds
+ * them.  Hit distances are those of the reference's primitive tests either
+ * way.  RT_HIP_BUILD=0 / 1 selects, for comparison, a linear BVH over Morton
+ * codes / a tree by locally-ordered clustering instead (ties between
+ * primitives hit at exactly the same t then follow that tree's leaf order). */
 int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
 
 /* Debug / test aid: the tree a handle holds, as RtNode records (2*k+1 nodes

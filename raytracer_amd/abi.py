@@ -23,6 +23,7 @@ RT_RNG_REF, RT_RNG_CTR = 0, 1
 RT_FLAG_TIME_KERNELS, RT_FLAG_COUNT_VISITS, RT_FLAG_EARLY_TERMINATE, RT_FLAG_REFERENCE_VISIT_RULE = 1, 2, 4, 8
 RT_FLAG_REUSE_PRIMARY_HITS = 16
 RT_MEM_HOST, RT_MEM_DEVICE = 0, 1
+RT_SPLIT_SAH, RT_SPLIT_MID = 0, 1  # RtScene.split_method
 RT_MAX_DEPTH_STATS = 16
 RT_NOALLOC_MAX_RAYS = 131072
 
@@ -80,7 +81,7 @@ class RtScene(C.Structure):
     _fields_ = [
         ("camera", RtCamera),
         ("n_nodes", C.c_int32), ("n_elements", C.c_int32), ("n_triangles", C.c_int32), ("n_quads", C.c_int32),
-        ("n_spheres", C.c_int32), ("n_materials", C.c_int32), ("n_attractors", C.c_int32), ("reserved", C.c_int32),
+        ("n_spheres", C.c_int32), ("n_materials", C.c_int32), ("n_attractors", C.c_int32), ("split_method", C.c_int32),
         ("nodes", C.POINTER(RtNode)),
         ("elements", C.POINTER(RtElementRef)),
         ("triangles", C.POINTER(RtTriangle)),

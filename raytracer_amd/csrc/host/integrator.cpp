@@ -99,6 +99,7 @@ class RenderIntegrator {
     pod.n_spheres = (int32_t)scene.spheres.size();
     pod.n_materials = (int32_t)scene.materials.size();
     pod.n_attractors = (int32_t)scene.attractors.size();
+    pod.split_method = (config.has_split_method ? config.split_method : SplitMethod::Mid) == SplitMethod::SAH ? RT_SPLIT_SAH : RT_SPLIT_MID;
     pod.nodes = scene.nodes.data();
     pod.elements = scene.element_refs.data();
     pod.triangles = scene.triangles.data();

@@ -39,10 +39,11 @@ RT_DEV float up32(double x) { return nextafterf(__double2float_ru(x), INFINITY);
 // `scene_bounds`: 6 ordered uints (min xyz, max xyz), initialised to 0xffffffff x3, 0 x3; `bad`: set if a box is not finite
 __global__ void __launch_bounds__(256) k_prim_bounds(int32_t n, const RtElementRef *elements, const RtTriangle *tris, const RtQuad *quads,
                                                       const RtSphere *spheres, Box32 *boxes, uint32_t *scene_bounds, uint32_t *bad) {
-  const int32_t n_round = (n + 63) & ~63;
-  for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_round; e += gridDim.x * blockDim.x) {
+  // bounds of what this thread has seen, as ordered uints
+  uint32_t smn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, smx[3] = {0u, 0u, 0u};
+  for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (e < n) {
+    {
       auto add = [&](double x, double y, double z) {
         lo[0] = fmin(lo[0], x); lo[1] = fmin(lo[1], y); lo[2] = fmin(lo[2], z);
         hi[0] = fmax(hi[0], x); hi[1] = fmax(hi[1], y); hi[2] = fmax(hi[2], z);
@@ -79,22 +80,27 @@ __global__ void __launch_bounds__(256) k_prim_bounds(int32_t n, const RtElementR
         for (int a = 0; a < 3; a++) b.mn[a] = b.mx[a] = 0.0f, lo[a] = hi[a] = 0.0;
       }
       boxes[e] = b;
-      for (int a = 0; a < 3; a++) lo[a] = b.mn[a], hi[a] = b.mx[a];
-    }
-    // wave reduction, then one atomic per wave and bound
-    for (int a = 0; a < 3; a++) {
-      uint32_t mn = e < n ? f32_ordered((float)lo[a]) : 0xffffffffu, mx = e < n ? f32_ordered((float)hi[a]) : 0u;
-      for (int off = 32; off > 0; off >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-      }
-      if ((threadIdx.x & 63) == 0) {
-        atomicMin(&scene_bounds[a], mn);
-        atomicMax(&scene_bounds[3 + a], mx);
-      }
+      for (int a = 0; a < 3; a++) smn[a] = min(smn[a], f32_ordered(b.mn[a])), smx[a] = max(smx[a], f32_ordered(b.mx[a]));
     }
   }
+  // wave reduction, then the workgroup's waves through LDS: one atomic per workgroup and bound
+  __shared__ uint32_t part[4][6];
+  for (int a = 0; a < 3; a++) {
+    uint32_t mn = smn[a], mx = smx[a];
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][a] = mn, part[threadIdx.x >> 6][3 + a] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    atomicMin(&scene_bounds[a], min(min(part[0][a], part[1][a]), min(part[2][a], part[3][a])));
+    atomicMax(&scene_bounds[3 + a], max(max(part[0][3 + a], part[1][3 + a]), max(part[2][3 + a], part[3][3 + a])));
+  }
 }
+
 
 RT_DEV uint64_t spread21(uint32_t v) {  // bit k of v -> bit 3k
   uint64_t x = v & 0x1fffffu;
@@ -540,7 +546,8 @@ static int scene_build_impl(const RtScene *s, int device, RtSceneHandle **out) {
   const int gi = grid_for(std::max(n_internal, 1), block, 256 * 8);
   // how the tree is made: 0 radix tree over Morton codes, 1 locally-ordered clustering, 2 / 3 the reference's own top-down
   // build with its bucketed surface-area heuristic / its midpoint split (rt_build_topdown.h)
-  const int method = n_internal > 0 ? tuning.build_method : 0;
+  if (s->split_method != RT_SPLIT_SAH && s->split_method != RT_SPLIT_MID) return fail(RT_ERR_BAD_ARG, "RtScene.split_method must be RT_SPLIT_SAH or RT_SPLIT_MID");
+  const int method = n_internal == 0 ? 0 : tuning.build_method >= 0 ? tuning.build_method : (s->split_method == RT_SPLIT_MID ? 3 : 2);
   const bool topdown = method >= 2, ploc = method == 1;
   hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(block), 0, st, n, d_elements, d_tris, d_quads, d_spheres, d_boxes, d_scene, d_bad);
   size_t sort_bytes = 0, scan_bytes = 0;

@@ -755,9 +755,10 @@ struct Tuning {
   int wide = -1, tri_pad = -1;  // -1: by size; 0 / 1: forced off / on
   int node_order = -1;          // -1: by size; 0: the reference's preorder; 1: line-sized blocks
   int no_grid = 0, no_exact_boxes = 0;
-  // rt_hip_scene_build: 0 = the radix tree over Morton codes, 1 = locally-ordered clustering (neighbours within ploc_radius places of
-  // the Morton order), 2 = the reference's top-down build with its bucketed surface-area heuristic, 3 = with its midpoint split
-  int build_method = 2, ploc_radius = 16;
+  // rt_hip_scene_build: -1 = the reference's top-down build by the rule RtScene.split_method names; 0 = the radix tree over Morton codes,
+  // 1 = locally-ordered clustering (neighbours within ploc_radius places of the Morton order), 2 / 3 = the reference's top-down build
+  // with its bucketed surface-area heuristic / its midpoint split whatever the scene says
+  int build_method = -1, ploc_radius = 16;
 };
 struct TuningName {
   const char *env, *name;
@@ -780,7 +781,7 @@ static const TuningName kTuningNames[] = {
     {"RT_HIP_TRI_PAD", "tri_pad", &Tuning::tri_pad, 0, 1, true},
     {"RT_HIP_NO_GRID", "no_grid", &Tuning::no_grid, 0, 1, true},
     {"RT_HIP_NO_EXACT_BOXES", "no_exact_boxes", &Tuning::no_exact_boxes, 0, 1, true},
-    {"RT_HIP_BUILD", "build_method", &Tuning::build_method, 0, 3, true},
+    {"RT_HIP_BUILD", "build_method", &Tuning::build_method, -1, 3, true},
     {"RT_HIP_PLOC_RADIUS", "ploc_radius", &Tuning::ploc_radius, 1, 32, true},
 };
 struct ExtendTuningName {

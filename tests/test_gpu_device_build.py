@@ -1,5 +1,6 @@
-"""rt_hip_scene_build: the BVH built on the device from the primitives alone (linear BVH over Morton codes), opt-in
-beside the default path that takes the host's reference-order tree.
+"""rt_hip_scene_build: the BVH built on the device from the primitives alone -- by default the reference's own top-down
+build run level by level on the GPU (same tree as the host's), for comparison a linear BVH over Morton codes or a tree by
+locally-ordered clustering (RT_HIP_BUILD=0 / 1) -- opt-in beside the default path that takes the host's reference-order tree.
 
 Checked against the CPU oracle walking the DOWNLOADED device tree (rt_hip_scene_download_tree): hit distances and
 element ids exact, ties included, since ties follow the depth-first leaf order of the tree that is walked.  Against
@@ -100,7 +101,8 @@ def test_top_down_device_build_makes_the_hosts_tree(which, split, tmp_scene_dir,
         ri = RenderIntegrator.new({"camera": scenes.camera(), "elements": [scenes.sphere((278, 278, 200), 120, scenes.lambertian(.5, .5, .5)),
                                                                          scenes.sphere((100, 278, 200), 50, scenes.lambertian(.5, .5, .5))]},
                                   scenes.config(16, 16, 2, 1, 1, split=split)).prepare()
-    monkeypatch.setenv("RT_HIP_BUILD", "2" if split == "SAH" else "3")
+    monkeypatch.delenv("RT_HIP_BUILD", raising=False)             # the scene names the rule (RtScene.split_method)
+    assert ri.scene.contents.split_method == (abi.RT_SPLIT_SAH if split == "SAH" else abi.RT_SPLIT_MID)
     dev = ResidentScene(ri.scene, 0, build_on_device=True)
     nodes = dev.download_tree()
     sc = ri.scene.contents
