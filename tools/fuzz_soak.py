@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Soak run of the random-scene parity check of tests/test_gpu_fuzz.py over many more seeds than the test suite holds:
 closest hits of random rays and primary hits against the oracle, bit for bit, and a whole render every eighth seed.
-tools/fuzz_soak.py FIRST LAST [IMAGE_EVERY=8] [--device-build]; with --device-build the tree is the linear BVH built on the
-device and the oracle walks the downloaded copy of it (rt_hip_scene_download_tree).  The RT_HIP_* environment (e.g. RT_HIP_WIDE=1 RT_HIP_TRI_PAD=1) picks the variant.
+tools/fuzz_soak.py FIRST LAST [IMAGE_EVERY=8] [--device-build]; with --device-build the tree is the one built on the
+device (by default the reference's top-down build: the run then also counts the scenes whose device-built tree is not the
+host's, node for node; RT_HIP_BUILD=0 / 1: the radix tree / the clustered one) and the oracle walks the downloaded copy of it
+(rt_hip_scene_download_tree).  The RT_HIP_* environment (e.g. RT_HIP_WIDE=1 RT_HIP_TRI_PAD=1) picks the variant.
 Pixels that differ in an image while every hit agrees are paths that a last-bit difference between the device's and libm's
 sin / cos / pow sends to the other side of an edge; the run counts them."""
 import os
@@ -25,6 +27,7 @@ from helpers import image_parity
 images = differing_pixels = images_with_differences = 0
 t0 = time.time()
 bad_seeds = []
+other_tree = []  # scenes whose device-built tree differs from the host's
 for seed in range(first, last):
     ri = _scene(seed)
     if device_build:
@@ -33,6 +36,11 @@ for seed in range(first, last):
         from test_gpu_device_build import _scene_with_nodes
         res = ResidentScene(ri.scene, 0, build_on_device=True)
         nodes = res.download_tree()
+        if os.environ.get("RT_HIP_BUILD", "-1") in ("-1", "2", "3"):
+            from test_gpu_device_build import _preorder
+            sc = ri.scene.contents
+            if _preorder(nodes, len(nodes)) != _preorder(sc.nodes, sc.n_nodes):
+                other_tree.append(seed)
         twin = _scene_with_nodes(ri, nodes)
         scene_for_oracle = C.byref(twin)
     else:
@@ -67,5 +75,5 @@ for seed in range(first, last):
     if (seed - first) % 25 == 24:
         print(f"  {seed - first + 1} seeds, {time.time() - t0:.0f} s, mismatching so far: {bad_seeds}", flush=True)
 print(f"seeds {first}..{last - 1}: {len(bad_seeds)} mismatching {bad_seeds}; {images} images of 1600 pixels rendered, {images_with_differences} with differing pixels, "
-      f"{differing_pixels} such pixels in all; {time.time() - t0:.0f} s", flush=True)
+      f"{differing_pixels} such pixels in all; {time.time() - t0:.0f} s" + (f"; device-built tree differs from the host's on {len(other_tree)} scenes {other_tree[:20]}" if device_build else ""), flush=True)
 sys.exit(1 if bad_seeds else 0)
