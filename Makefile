@@ -15,7 +15,7 @@ hip: $(LIBDIR)/librt_hip.so
 host: $(LIBDIR)/librt_host.so
 oracle: oracle/_build/librt_oracle.so
 
-$(LIBDIR)/librt_hip.so: raytracer_amd/csrc/rt_hip.hip raytracer_amd/csrc/rt_device.h raytracer_amd/csrc/rt_build_device.h raytracer_amd/csrc/rt_build_topdown.h include/rt_hip.h
+$(LIBDIR)/librt_hip.so: raytracer_amd/csrc/rt_hip.hip raytracer_amd/csrc/rt_device.h raytracer_amd/csrc/rt_build_device.h raytracer_amd/csrc/rt_build_topdown.h raytracer_amd/csrc/rt_comm.h include/rt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -o $@ raytracer_amd/csrc/rt_hip.hip
 

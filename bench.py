@@ -58,6 +58,9 @@ def parse_args(argv=None):
                     help="exactly one render and nothing else on the GPU (for rocprofv3 counter passes): implies --steps 1 --warmup 0, "
                          "no CPU baseline, no instrumented render")
     ap.add_argument("--no-reuse-leg", action="store_true", help="skip the extra renders with RT_FLAG_REUSE_PRIMARY_HITS")
+    ap.add_argument("--c-gather", action="store_true",
+                    help="gather inside librt_hip.so (rt_hip_render_ranks: RCCL sends and receives issued by the C library) instead of "
+                         "torch.distributed's gather; the render and the sharding are the same")
     ap.add_argument("--dry-run", action="store_true", help="print the launch plan (child command and environment) and exit")
     args = ap.parse_args(argv)
     if args.profile_pass:
@@ -264,7 +267,23 @@ def main():
     if rank == 0:
         host_planes = torch.empty(2, H, W, 3, dtype=torch.float64, pin_memory=True)
 
+    comm = None
+    if args.c_gather:  # the communicator of the C library: rank 0's id reaches the others through torch's store
+        idt = torch.zeros(abi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(parallel.RankComm.new_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idt, 0)
+        comm = parallel.RankComm(idt.cpu().numpy().tobytes(), rank, world, local_rank)
+        whole = torch.empty(2, H, W, 3, dtype=torch.float64, device=dev) if rank == 0 else None
+
     def step():
+        if comm is not None:
+            _, st = comm.render(res, cfg, device_out={"pixels": whole[0], "sample_pixels": whole[1]} if rank == 0 else None)
+            if rank == 0:
+                host_planes.copy_(whole, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return st
         _, st = res.render(cfg, device_out=out)  # (`cfg` is looked up at call time: the reuse leg below swaps it)
         full = parallel.gather_rows(planes, H, rank, world, row_block=row_block, row_dim=1)
         if rank == 0:
@@ -312,6 +331,8 @@ def main():
     else:
         trace_ms_max = trace_ms
     rays_all, launches_all, samples_all = float(tot[1]), float(tot[3]), float(tot[4])
+    if comm is not None:  # rt_hip_render_ranks already reports the job's query and sample counts on every rank
+        rays_all, samples_all = float(rays), float(samples)
 
     # ---- beside the headline: the same image with RT_FLAG_REUSE_PRIMARY_HITS (every primary ray traced once per round
     # instead of once per batch: identical pixels, fewer queries executed than the reference makes).  Timed like the
@@ -336,6 +357,8 @@ def main():
             dist.all_reduce(mxr, op=dist.ReduceOp.MAX)
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
             t_reuse = float(mxr[0])
+            if comm is not None:
+                tr[1], tr[2] = float(st_r.rays), float(st_r.rays_traced)
         reuse = {"flag": "RT_FLAG_REUSE_PRIMARY_HITS", "steps": n_reuse, "time_to_image_s": t_reuse,
                  "rays_reference_equivalent_per_step": float(tr[1]), "rays_executed_per_step": float(tr[2]),
                  "mrays_executed_per_s": float(tr[2]) / t_reuse / 1e6,
@@ -485,7 +508,8 @@ def main():
                             f"(min {cfg.min_sample_batches}), depth {cfg.max_depth}, SAH BVH, adaptive z-test",
                 "elements": sc.n_elements, "bvh_nodes": sc.n_nodes, "bvh_depth": ri.bvh_depth(),
                 "rows_per_rank": n_rows, "row_block": row_block,
-                "parallelism": f"blocks of {row_block} row(s) dealt over {world} GPU(s), one gather to rank 0",
+                "parallelism": f"blocks of {row_block} row(s) dealt over {world} GPU(s), one gather to rank 0"
+                               + (" inside librt_hip.so (rt_hip_render_ranks: RCCL sends and receives)" if comm is not None else ""),
                 "early_terminate": bool(args.early_terminate), "reference_visit_rule": bool(args.reference_visits),
             },
             "rays_per_step": rays_all / args.steps,

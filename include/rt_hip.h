@@ -347,6 +347,27 @@ int rt_hip_trace_rays(RtSceneHandle *handle, int64_t n, const double *origins,
  * primitives hit at exactly the same t then follow that tree's leaf order). */
 int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
 
+/* ---- one image, several processes (one per GPU).  The reference deals the rows of the image to the threads of one
+ * process (integrator.rs:226-243, Rayon); here rank r of `world` renders the row blocks r, r + world, ... on its own GPU
+ * and rank 0 receives every rank's rows over RCCL (xGMI between the GPUs of a node) and assembles the image on its
+ * device.  Pixels are independent given the scene, so this one exchange is all the traffic there is.
+ *   rt_hip_comm_id      rank 0 makes an id (ncclGetUniqueId) and hands a copy to every rank by the caller's own means
+ *                       (a file, an environment variable, MPI, a socket);
+ *   rt_hip_comm_init    every rank, with the same id: collective (ncclCommInitRank), binds the communicator to `device`;
+ *   rt_hip_render_ranks every rank, with its own handle of the same scene on that device and the same cfg (its
+ *                       row_first / row_stride are set by the call; row_block is kept): collective.  On rank 0 `out`
+ *                       receives the WHOLE image (pixels and, if not NULL, sample_pixels; host or device pointers by
+ *                       out->memory; the other outputs must be NULL); on the other ranks `out` may be NULL.  stats:
+ *                       rays, samples, rays_traced and rays_by_depth are the job's totals on every rank, the rest is
+ *                       the calling rank's.
+ * RCCL is loaded (dlopen) when the first id or communicator is made; a process that never calls these never loads it. */
+typedef struct RtComm RtComm;
+#define RT_COMM_ID_BYTES 128
+int rt_hip_comm_id(unsigned char id[RT_COMM_ID_BYTES]);
+int rt_hip_comm_init(const unsigned char id[RT_COMM_ID_BYTES], int rank, int world, int device, RtComm **out);
+int rt_hip_comm_free(RtComm *comm);
+int rt_hip_render_ranks(RtSceneHandle *handle, RtComm *comm, const RtConfig *cfg, RtImage *out, RtStats *stats);
+
 /* Debug / test aid: the tree a handle holds, as RtNode records (2*k+1 nodes
  * for k internal nodes: the root first, every leaf after the internal nodes;
  * child boxes are the f32 boxes the device tests).  With nodes == NULL only

@@ -165,7 +165,9 @@ HIP_SYMBOLS = [
     "rt_hip_last_error", "rt_hip_device_count", "rt_hip_scene_upload", "rt_hip_scene_free",
     "rt_hip_render_resident", "rt_hip_render", "rt_hip_primary_hits", "rt_hip_trace_rays", "rt_hip_set_progress",
     "rt_hip_trace_rays_noalloc", "rt_hip_scene_build", "rt_hip_scene_download_tree", "rt_hip_scene_tune",
+    "rt_hip_comm_id", "rt_hip_comm_init", "rt_hip_comm_free", "rt_hip_render_ranks",
 ]
+RT_COMM_ID_BYTES = 128
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
     "rt_host_last_error", "rt_host_new_from_json", "rt_host_new_from_strings", "rt_host_free", "rt_host_prepare",
@@ -204,6 +206,10 @@ def hip_lib():
         lib.rt_hip_scene_download_tree.argtypes = [C.c_void_p, C.POINTER(RtNode), C.c_int32, C.POINTER(C.c_int32)]
         lib.rt_hip_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_hip_scene_tune.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.rt_hip_comm_id.argtypes = [C.c_char_p]
+        lib.rt_hip_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.rt_hip_comm_free.argtypes = [C.c_void_p]
+        lib.rt_hip_render_ranks.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RtConfig), C.POINTER(RtImage), C.POINTER(RtStats)]
         _hip = lib
     return _hip
 

@@ -3161,8 +3161,21 @@ static int noalloc_warm_up(RtSceneHandle *h) {
 }
 
 #include "rt_build_device.h"
+#include "rt_comm.h"
 
 // ------------------------------------------------------- the C entry points
+int rt_hip_comm_id(unsigned char *id) {
+  return guarded([&] { return comm_id_impl(id); });
+}
+int rt_hip_comm_init(const unsigned char *id, int rank, int world, int device, RtComm **out) {
+  return guarded([&] { return comm_init_impl(id, rank, world, device, out); });
+}
+int rt_hip_comm_free(RtComm *comm) {
+  return guarded([&] { return comm_free_impl(comm); });
+}
+int rt_hip_render_ranks(RtSceneHandle *handle, RtComm *comm, const RtConfig *cfg, RtImage *out, RtStats *stats) {
+  return guarded([&] { return render_ranks_impl(handle, comm, cfg, out, stats); });
+}
 int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out) {
   return guarded([&] { return scene_build_impl(scene, device, out); });
 }

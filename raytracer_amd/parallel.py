@@ -99,3 +99,60 @@ def interleave_numpy(parts, height, row_block=ROW_BLOCK):
         rows = shard_rows(height, r, world, row_block)
         full[rows] = parts[r][: len(rows)]
     return full
+
+
+class RankComm:
+    """A communicator of the C library (rt_hip_comm_init): the gather runs inside librt_hip.so over RCCL, without
+    torch.distributed.  `comm_id` is made once by rank 0 (RankComm.new_id()) and handed to every rank by the caller."""
+
+    @staticmethod
+    def new_id():
+        import ctypes as C
+        from . import abi
+        buf = C.create_string_buffer(abi.RT_COMM_ID_BYTES)
+        abi.check_hip(abi.hip_lib().rt_hip_comm_id(buf))
+        return buf.raw
+
+    def __init__(self, comm_id, rank, world, device):
+        import ctypes as C
+        from . import abi
+        assert len(comm_id) == abi.RT_COMM_ID_BYTES
+        self._c = C.c_void_p()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        abi.check_hip(abi.hip_lib().rt_hip_comm_init(comm_id, self.rank, self.world, self.device, C.byref(self._c)))
+
+    def close(self):
+        from . import abi
+        if self._c:
+            abi.hip_lib().rt_hip_comm_free(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, resident, cfg, device_out=None):
+        """rt_hip_render_ranks: collective.  Rank 0 gets the whole image (numpy arrays `pixels`, `sample_pixels`, or written
+        into the torch CUDA tensors of `device_out`); the other ranks get None.  Returns (image or None, RtStats)."""
+        import ctypes as C
+        from . import abi
+        stats = abi.RtStats()
+        img = abi.RtImage()
+        out = None
+        if self.rank == 0:
+            if device_out is not None:
+                img.memory = abi.RT_MEM_DEVICE
+                img.pixels = device_out["pixels"].data_ptr()
+                if device_out.get("sample_pixels") is not None:
+                    img.sample_pixels = device_out["sample_pixels"].data_ptr()
+                out = device_out
+            else:
+                out = {"pixels": np.empty((cfg.img_height, cfg.img_width, 3), dtype=np.float64),
+                       "sample_pixels": np.empty((cfg.img_height, cfg.img_width, 3), dtype=np.float64)}
+                img.memory = abi.RT_MEM_HOST
+                img.pixels = out["pixels"].ctypes.data
+                img.sample_pixels = out["sample_pixels"].ctypes.data
+        abi.check_hip(abi.hip_lib().rt_hip_render_ranks(resident._h, self._c, C.byref(cfg), C.byref(img) if self.rank == 0 else None, C.byref(stats)))
+        return out, stats
