@@ -116,6 +116,36 @@ def test_top_down_device_build_makes_the_hosts_tree(which, split, tmp_scene_dir,
     dev.close()
 
 
+@pytest.mark.parametrize("split", ["SAH", "Mid"])
+def test_top_down_device_build_on_coinciding_centroids_and_tiny_scenes(split, monkeypatch):
+    """Elements whose centroids coincide are split into halves by position (bvh_node_sah.rs:351-362), which makes the ORDER the
+    earlier bucket sorts left behind visible in the tree: 37 copies of one triangle, 5 of another one with the same centroid
+    and a few spheres must come out as the host's tree, and a ray through the copies must name the same copy as on the
+    host's tree (the last one in leaf order, interval.rs:31-33).  Scenes of 3, 4 and 5 elements: the smallest recursions."""
+    monkeypatch.delenv("RT_HIP_BUILD", raising=False)
+    tri = lambda a, b, c: {"JSONTriangle": {"v0": scenes._v(*a), "v1": scenes._v(*b), "v2": scenes._v(*c), "material": scenes.lambertian(.5, .5, .5)}}
+    copies = [tri((100, 100, 300), (300, 100, 300), (200, 300, 300)) for _ in range(37)]
+    # same bounding box, hence the same centroid, other triangle
+    copies += [tri((100, 100, 300), (300, 300, 300), (200, 100, 300)) for _ in range(5)]
+    spheres = [scenes.sphere((60 + 90 * k, 420, 250), 30, scenes.lambertian(.5, .5, .5)) for k in range(5)]
+    for elements in (copies + spheres, spheres[:3], spheres[:4], spheres[:5], copies[:3]):
+        ri = RenderIntegrator.new({"camera": scenes.camera(), "elements": elements}, scenes.config(16, 16, 2, 1, 1, split=split)).prepare()
+        dev = ResidentScene(ri.scene, 0, build_on_device=True)
+        nodes = dev.download_tree()
+        sc = ri.scene.contents
+        assert _preorder(nodes, len(nodes)) == _preorder(sc.nodes, sc.n_nodes)
+        rng = np.random.RandomState(5)
+        o = np.tile(np.array([200.0, 170.0, -400.0]), (2000, 1)) + rng.normal(scale=40.0, size=(2000, 3)) * np.array([1, 1, 0])
+        d = np.tile(np.array([0.0, 0.0, 1.0]), (2000, 1)) + rng.normal(scale=0.05, size=(2000, 3))
+        ph, th = ri.resident(0).trace_rays(o, d)
+        pd, td = dev.trace_rays(o, d)
+        assert np.array_equal(th, td) and np.array_equal(ph, pd)
+        if len(elements) > 40:
+            assert (ph >= 0).mean() > 0.3                                 # the stack of copies is hit (and one copy of it wins every tie)
+        dev.close()
+        ri.close()
+
+
 @pytest.mark.parametrize("method", [0, 1, 2, 3])
 @pytest.mark.parametrize("which", ["c1", "knot", "tilted", "single"])
 def test_device_built_tree_gives_the_oracles_hits(which, method, tmp_scene_dir, monkeypatch):
