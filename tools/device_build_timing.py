@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--soup", action="store_true", help="the triangle soup of BASELINE's largest configuration instead of the mesh (batches of 16, up to 4)")
     ap.add_argument("--no-count", action="store_true", help="time the production kernels (the visit-counting ones run at four waves per SIMD)")
     ap.add_argument("--split", default="SAH", help="the host build's bvh_split_method (SAH or Mid)")
+    ap.add_argument("--methods", default="", help="comma-separated RT_HIP_BUILD values: the device leg once per method (-1 the scene's rule = the reference's top-down build, "
+                                                 "0 radix tree, 1 clustering, 2 / 3 top-down bucketed / midpoint)")
     ap.add_argument("--only-device", action="store_true", help="skip the host-built tree's renders")
     ap.add_argument("--reupload", action="store_true", help="also: the device-built tree downloaded and uploaded again like a host-built one (tree shape apart from record layout)")
     args = ap.parse_args()
@@ -61,17 +63,34 @@ def main():
                         "bvh_depth": ri.bvh_depth()}
     host.close()
     # device path: the same primitives (the host's tree is ignored), tree built on the GPU
-    t5 = time.perf_counter()
-    dev = ResidentScene(ri.scene, 0, build_on_device=True)
-    t6 = time.perf_counter()
-    dev.render(cfg)
-    t7 = time.perf_counter()
-    _, sd = dev.render(cfg)
-    t8 = time.perf_counter()
-    out["device_tree"] = {"copy_and_build_s": t6 - t5, "first_render_s": t7 - t6, "render_s": t8 - t7, "mrays_per_s": sd.rays / (t8 - t7) / 1e6,
-                          "extend_ms": sd.trace_kernel_ms, "shade_ms": sd.shade_kernel_ms,
-                          "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1),
-                          "stack_block_moves_per_ray": sd.stack_block_moves / max(sd.rays_traced, 1), "bvh_depth": dev.bvh_depth() if hasattr(dev, "bvh_depth") else None}
+    def device_leg():
+        t5 = time.perf_counter()
+        dev = ResidentScene(ri.scene, 0, build_on_device=True)
+        t6 = time.perf_counter()
+        dev.render(cfg)
+        t7 = time.perf_counter()
+        _, sd = dev.render(cfg)
+        t8 = time.perf_counter()
+        leg = {"copy_and_build_s": t6 - t5, "first_render_s": t7 - t6, "render_s": t8 - t7, "mrays_per_s": sd.rays / (t8 - t7) / 1e6,
+               "extend_ms": sd.trace_kernel_ms, "shade_ms": sd.shade_kernel_ms,
+               "node_visits_per_ray": sd.node_visits / max(sd.rays_traced, 1), "leaf_tests_per_ray": sd.leaf_tests / max(sd.rays_traced, 1),
+               "stack_block_moves_per_ray": sd.stack_block_moves / max(sd.rays_traced, 1)}
+        return dev, sd, leg
+
+    if args.methods:
+        names = {"-1": "the scene's rule (the reference's top-down build)", "0": "radix tree over Morton codes", "1": "locally-ordered clustering",
+                 "2": "the reference's top-down build, bucketed surface-area split", "3": "the reference's top-down build, midpoint split"}
+        out["device_tree_by_method"] = {}
+        for m in args.methods.split(","):
+            os.environ["RT_HIP_BUILD"] = m
+            ResidentScene(ri.scene, 0, build_on_device=True).close()  # (a first build of the process pays for its code objects)
+            dev_m, _, leg = device_leg()
+            leg["method"] = names.get(m, m)
+            out["device_tree_by_method"][m] = leg
+            dev_m.close()
+        os.environ.pop("RT_HIP_BUILD", None)
+    dev, sd, out["device_tree"] = device_leg()
+    out["device_tree"]["bvh_depth"] = None
     if args.reupload:
         import ctypes as C
         import numpy as np
