@@ -1023,7 +1023,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q,
   __shared__ double lds_f64[13][kShadeBlock];  // point, normal, throughput, direction (3 each), material parameter
   __shared__ uint64_t lds_rng[kShadeBlock];
   __shared__ uint32_t lds_pid[kShadeBlock], lds_bits[kShadeBlock];
-  __shared__ uint32_t lds_counts[kShadeCategories][kShadeWaves];  // continuing paths per category and wave
+  // continuing paths per category and wave, one set per parity of the trip: a wave writes the next trip's counts before that trip's
+  // first barrier, while a slower wave may still be reading this trip's after its second one
+  __shared__ uint32_t lds_counts_all[2][kShadeCategories][kShadeWaves];
+  uint32_t trip_parity = 0;
   const bool staged = sc.n_materials <= kLdsMaterials;
   if (staged) {
     const uint32_t words = (uint32_t)sc.n_materials * (uint32_t)(sizeof(DevMaterial) / 4);
@@ -1043,6 +1046,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PathQueue q,
   uint32_t ref_ahead = (!REUSE && jj0 < n) ? hits.ref[in0 + jj0] : kRefNone;
   for (uint32_t jj = jj0; jj - threadIdx.x < n_round; jj += stride) {
     const uint32_t j = in0 + jj;
+    uint32_t (*lds_counts)[kShadeWaves] = lds_counts_all[trip_parity];
+    trip_parity ^= 1u;
     const uint32_t ref_now = ref_ahead;
     if (!REUSE) ref_ahead = (jj + stride < n) ? hits.ref[j + stride] : kRefNone;
     // ---- phase A: load, classify, decide whether the path goes on
