@@ -130,6 +130,10 @@ struct RenderParams {
   // order of the pixels in the active list (see pixel_of_key)
   uint32_t tiles_x, n_tiles, tile_mult, tile_inv;
   uint32_t tile_wlog, tile_hlog;  // a tile is 2^wlog pixels wide and 2^hlog rows of the shard high (64 pixels)
+  // The per-pixel working arrays (filter weights, running sums, per-batch history) are indexed by KEY, not by pixel: neighbouring
+  // entries of the active list have neighbouring keys, so a wave's 64 lanes read 512 consecutive bytes of them whatever the shape
+  // of a tile in the image (indexed by pixel, an 8 x 8 tile is eight runs of 64 bytes: generate + accumulate 51 -> 42 ms).
+  uint64_t n_keys;  // n_tiles * 64 >= n_pix (tiles at the image's edge hold keys no pixel has)
 };
 
 // The active list holds sort keys, not pixel numbers, and is kept sorted.  A key names a 64-pixel
@@ -177,13 +181,14 @@ __device__ __forceinline__ uint32_t xcd_logical_block(uint32_t b, uint32_t nbloc
 // rays, and paths that end at the same bounce store neighbouring result records.  The Sobol index restarts with
 // every batch (integrator.rs:285): sample i of a pixel has the same offset, filter weight and -- without a lens --
 // the same direction in every batch; the paths of its G batches in a round differ in their random-number stream only
-// (and, with a lens, in the origin it draws).  The weight is stored once, by batch 0, as weights[i * n_pix + p].
+// (and, with a lens, in the origin it draws).  The weight is stored once, by batch 0, as weights[i * n_keys + key].
 struct GenSample {  // what the batches of one (pixel, sample i) share
   d3 pixel_sample, dir;
   uint64_t pixel_key;
 };
 RT_DEV GenSample generate_sample(const DevScene &sc, const RenderParams &rp, const uint32_t *active, uint32_t slot, uint32_t i, int32_t batch0, double *weights) {
-  const uint32_t p = pixel_of_key(rp, active[slot]);
+  const uint32_t key = active[slot];
+  const uint32_t p = pixel_of_key(rp, key);
   const int32_t x = (int32_t)(p % (uint32_t)rp.width);
   const int32_t y = image_row(rp, p / (uint32_t)rp.width);
   // integrator.rs:275: pixel_num = x * y (product), truncated to u32 as the Sobol seed
@@ -192,7 +197,7 @@ RT_DEV GenSample generate_sample(const DevScene &sc, const RenderParams &rp, con
   const double sy = ((double)sobol_sample(i, 1, sobol_seed) * rp.pixel_radius) - rp.pixel_radius / 2.;
   if (batch0 == 0) {
     const double inv_r = 1.0 / rp.pixel_radius;  // filter.rs:33-42
-    weights[(size_t)i * (size_t)rp.n_pix + p] = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
+    weights[(size_t)i * (size_t)rp.n_keys + key] = mitchell_1d(sx * inv_r, rp.filter_b, rp.filter_c) * mitchell_1d(sy * inv_r, rp.filter_b, rp.filter_c);
   }
   // camera.rs:95-120
   const d3 pixel_loc = ld3(sc.camera.pixel00_loc) + (ld3(sc.camera.pixel_delta_u) * (double)x) + (ld3(sc.camera.pixel_delta_v) * (double)y);
@@ -1292,7 +1297,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
     }
   }
   int32_t n_round = (n_slots + 63) & ~63;
-  size_t np = (size_t)rp.n_pix;
+  const size_t np = (size_t)rp.n_keys;  // stride of the per-pixel working arrays, which are indexed by key
   const uint32_t lane = threadIdx.x & 63u;
   // per-wave staging tile: 64 slots x 128 bytes, rows padded to 144 bytes against bank conflicts
   __shared__ double2 tile_all[4][64 * 9];
@@ -1308,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
     if (valid) {
       key = active[slot];
       p = pixel_of_key(rp, key);
-      ps = sums + p;
+      ps = sums + key;
       if (batch0) {
         sr = ps[0]; sg = ps[np]; sb = ps[2 * np]; sw = ps[3 * np];
       }
@@ -1316,7 +1321,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
     bool done = !valid;
     double mr = 0.0, mg = 0.0, mb = 0.0;
     int nb = batch0;
-    const double *ww = weights + p;
+    const double *ww = weights + key;
     // The batches of the round are handled kAccChunk at a time, in three passes that together
     // perform, per pixel, exactly the operations of the reference's batch loop in its order:
     //   1. per batch: the ordered sum of its samples, Stats::push, the running mean;
@@ -1394,8 +1399,8 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
             rays_v[gi] = nr;
             // the variance needs every batch again (the mean moved): keep its illuminance_approx and weight
             if (hist) {
-              hist[(size_t)(kb + gi) * 2 * np + p] = (cr + cr + cb + cg + cg + cg) / 6.0;
-              hist[(size_t)(kb + gi) * 2 * np + np + p] = bw;
+              hist[(size_t)(kb + gi) * 2 * np + key] = (cr + cr + cb + cg + cg + cg) / 6.0;
+              hist[(size_t)(kb + gi) * 2 * np + np + key] = bw;
             }
           }
         }
@@ -1405,7 +1410,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
         double ml[kAccChunk];
 #pragma unroll
         for (int gi = 0; gi < kAccChunk; gi++) ml[gi] = (mrv[gi] + mrv[gi] + mbv[gi] + mgv[gi] + mgv[gi] + mgv[gi]) / 6.0;
-        const double *hp = hist + p;
+        const double *hp = hist + key;
         int k = 0;
         for (; k + 4 <= kb; k += 4) {  // entries every batch of the chunk folds
           double hl[4], hw[4];
@@ -1772,6 +1777,7 @@ RenderParams make_params(const RtConfig *cfg, const Tuning &tuning) {
   rp.tile_wlog = 2 * kTileLog - rp.tile_hlog;
   rp.tiles_x = ((uint32_t)cfg->img_width + (1u << rp.tile_wlog) - 1u) >> rp.tile_wlog;
   rp.n_tiles = rp.tiles_x * (((uint32_t)shard_rows(cfg) + (1u << rp.tile_hlog) - 1u) >> rp.tile_hlog);
+  rp.n_keys = (uint64_t)rp.n_tiles << (2 * kTileLog);
   auto gcd = [](uint64_t a, uint64_t b) {
     while (b) {
       uint64_t t = a % b;
@@ -2724,10 +2730,10 @@ static int render_resident_impl(RtSceneHandle *h, const RtConfig *cfg, RtImage *
       HIP_TRY(sc.alloc(&primary_hits.ref, pe));
     }
     HIP_TRY(sc.alloc(&results.rec, cap_paths));
-    HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)n_pix));
-    HIP_TRY(sc.alloc(&sums, 4 * (size_t)n_pix));
+    HIP_TRY(sc.alloc(&weights, (size_t)S * (size_t)rp.n_keys));
+    HIP_TRY(sc.alloc(&sums, 4 * (size_t)rp.n_keys));
     // per-batch (illuminance_approx, weight) history, needed only if the z-test can ever run
-    if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)n_pix));
+    if (rp.max_batches - 1 > rp.min_batches) HIP_TRY(sc.alloc(&hist, (size_t)rp.max_batches * 2 * (size_t)rp.n_keys));
     HIP_TRY(sc.alloc(&active[0], n_pix));
     HIP_TRY(sc.alloc(&active[1], n_pix));
     HIP_TRY(sc.alloc(&counters, n_counters));
