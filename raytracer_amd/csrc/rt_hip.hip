@@ -1399,8 +1399,7 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
             rays_v[gi] = nr;
             // the variance needs every batch again (the mean moved): keep its illuminance_approx and weight
             if (hist) {
-              hist[(size_t)(kb + gi) * 2 * np + key] = (cr + cr + cb + cg + cg + cg) / 6.0;
-              hist[(size_t)(kb + gi) * 2 * np + np + key] = bw;
+              reinterpret_cast<double2 *>(hist)[(size_t)(kb + gi) * np + key] = make_double2((cr + cr + cb + cg + cg + cg) / 6.0, bw);
             }
           }
         }
@@ -1410,14 +1409,15 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
         double ml[kAccChunk];
 #pragma unroll
         for (int gi = 0; gi < kAccChunk; gi++) ml[gi] = (mrv[gi] + mrv[gi] + mbv[gi] + mgv[gi] + mgv[gi] + mgv[gi]) / 6.0;
-        const double *hp = hist + key;
+        const double2 *hp = reinterpret_cast<const double2 *>(hist) + key;  // per batch and key: (illuminance_approx, weight), one 16-byte load
         int k = 0;
         for (; k + 4 <= kb; k += 4) {  // entries every batch of the chunk folds
           double hl[4], hw[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            hl[u] = hp[(size_t)(k + u) * 2 * np];
-            hw[u] = hp[(size_t)(k + u) * 2 * np + np];
+            const double2 e = hp[(size_t)(k + u) * np];
+            hl[u] = e.x;
+            hw[u] = e.y;
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -1429,7 +1429,8 @@ __global__ void __launch_bounds__(256) k_accumulate(RenderParams rp, const uint3
           }
         }
         for (; k < kb + gc; k++) {  // the rest, and the chunk's own entries: batch gi folds entries 0..kb+gi
-          double hl = hp[(size_t)k * 2 * np], hw = hp[(size_t)k * 2 * np + np];
+          const double2 e = hp[(size_t)k * np];
+          const double hl = e.x, hw = e.y;
 #pragma unroll
           for (int gi = 0; gi < kAccChunk; gi++) {
             if (k <= kb + gi) {
