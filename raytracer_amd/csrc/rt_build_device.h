@@ -1,20 +1,30 @@
 // BVH construction on the device (opt-in, rt_hip_scene_build): where the reference builds its tree on the
 // host (BVH_SAH::build, /root/reference/src/bvh/bvh_node_sah.rs:147-159, 256-461) and the default path
-// of this library takes that tree as input, this builder makes its own from the primitives alone:
+// of this library takes that tree as input, this builder makes the tree from the primitives alone.
 //
-//   1. k_prim_bounds   true bounds of every element (f32, rounded outward), scene bounds by atomics
-//   2. k_morton        63-bit Morton code of every box centre; radix sort of (code, element)
-//   3. k_karras        the binary radix tree over the sorted codes (Karras 2012): every internal node
-//                      finds its range and split with no communication
-//   4. k_refit_pass    child boxes and subtree heights bottom-up, one tree level per launch (a kernel
-//                      boundary is the only synchronisation: no hand-off between workgroups in flight)
-//   5. k_emit_*        the records k_extend reads: 64-byte f32 nodes, 32-byte grid nodes, primitive
-//                      records in leaf (= Morton) order
+// By default it is the reference's own tree: the top-down recursion of BVHNode_SAH::build run level by level
+// (rt_build_topdown.h), by the split rule RtScene.split_method names.  Two other ways to a tree are kept for
+// comparison (RT_HIP_BUILD=0 / 1), both over the primitives in Morton order:
+//
+//   k_morton + radix sort   63-bit Morton code of every box centre
+//   k_karras                the binary radix tree over the sorted codes (Karras 2012): every internal node
+//                           finds its range and split with no communication; or
+//   k_ploc_*                locally-ordered clustering (Meister and Bittner 2018): clusters that choose each
+//                           other as cheapest neighbour merge, until one is left
+//
+// Shared by all three:
+//
+//   k_prim_bounds   true bounds of every element (f32, rounded outward), scene bounds by atomics
+//   k_refit_pass    child boxes and subtree heights bottom-up, one tree level per launch (a kernel
+//                   boundary is the only synchronisation: no hand-off between workgroups in flight)
+//   k_emit_*        the records k_extend reads: 64-byte f32 nodes, 32-byte grid nodes, primitive
+//                   records in leaf order
 //
 // Included by rt_hip.hip (one translation unit with the handle, the kernels and the error plumbing).
-// What differs from a tree built the reference's way: boxes are the primitives' TRUE bounds (the reference
-// boxes a quad by two corners, quad.rs:86), so every box bounds its contents and the order-free walk
-// always applies; exact-t ties between primitives are decided by THIS tree's depth-first leaf order.
+// What differs from an uploaded tree: boxes are the primitives' TRUE bounds (the reference boxes a quad by two
+// corners, quad.rs:86), so every box bounds its contents and the order-free walk always applies; exact-t ties
+// between primitives are decided by the built tree's depth-first leaf order (the reference's, with the default
+// method).
 #pragma once
 
 namespace build {
