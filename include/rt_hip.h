@@ -360,6 +360,8 @@ int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
  *                       out->memory; the other outputs must be NULL); on the other ranks `out` may be NULL.  stats:
  *                       rays, samples, rays_traced and rays_by_depth are the job's totals on every rank, the rest is
  *                       the calling rank's.
+ * The calls are collective and blocking: a rank that returns an error before the exchange (bad arguments, out of
+ * memory) leaves the others waiting for it, so a caller that sees an error tears the job down, as with any RCCL program.
  * RCCL is loaded (dlopen) when the first id or communicator is made; a process that never calls these never loads it. */
 typedef struct RtComm RtComm;
 #define RT_COMM_ID_BYTES 128
