@@ -44,6 +44,12 @@ void rt_host_free(RtHostIntegrator *h);
 /* integrator.rs:163-192.  Idempotent. */
 int rt_host_prepare(RtHostIntegrator *h);
 
+/* Opt-in, before rt_host_prepare: leave BVH_SAH::build (integrator.rs:183-189) to the GPU.  rt_host_prepare then
+ * makes no tree (RtScene.nodes is NULL, n_nodes 0; rt_host_bvh_depth returns -1) and rt_host_render /
+ * rt_host_render_devices set their scenes up with rt_hip_scene_build, which runs the same top-down build by the
+ * same split rule on the device (2 M triangles: 10 ms instead of 0.24 s of build and 0.25 s of upload). */
+int rt_host_set_device_build(RtHostIntegrator *h, int on);
+
 /* Valid after rt_host_prepare; owned by the integrator. */
 const RtScene *rt_host_scene(RtHostIntegrator *h);
 /* The Config as the RtConfig POD (row shard = whole image, RT_RNG_CTR).

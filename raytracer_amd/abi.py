@@ -172,7 +172,7 @@ RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
 HOST_SYMBOLS = [
     "rt_host_last_error", "rt_host_new_from_json", "rt_host_new_from_strings", "rt_host_free", "rt_host_prepare",
     "rt_host_scene", "rt_host_config", "rt_host_bvh_depth", "rt_host_element_bbox", "rt_host_render", "rt_host_render_devices",
-    "rt_host_pixels", "rt_host_sample_pixels", "rt_host_set_pixels", "rt_host_save_to_png",
+    "rt_host_pixels", "rt_host_sample_pixels", "rt_host_set_pixels", "rt_host_save_to_png", "rt_host_set_device_build",
 ]
 
 _hip = None
@@ -237,6 +237,7 @@ def host_lib():
         lib.rt_host_element_bbox.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.rt_host_render.argtypes = [C.c_void_p, C.c_int, C.POINTER(RtStats)]
         lib.rt_host_render_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(RtStats)]
+        lib.rt_host_set_device_build.argtypes = [C.c_void_p, C.c_int]
         lib.rt_host_pixels.argtypes = [C.c_void_p]
         lib.rt_host_pixels.restype = C.POINTER(C.c_double)
         lib.rt_host_sample_pixels.argtypes = [C.c_void_p]

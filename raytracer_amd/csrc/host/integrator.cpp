@@ -33,6 +33,7 @@ class RenderIntegrator {
   RtScene pod{};
   RtConfig pod_config{};
   bool prepared = false;
+  bool device_build = false;  // leave BVH_SAH::build to the GPU (rt_hip_scene_build): prepare() then makes no tree
   RtSceneHandle *resident = nullptr;
   int resident_device = -1;
   // one copy of the scene per entry of the device list of render_devices()
@@ -84,7 +85,7 @@ class RenderIntegrator {
     expand_elements(scene_json, base_dir, scene);
     if (scene.elements.empty()) throw std::runtime_error("scene has no elements");
     auto t1 = std::chrono::steady_clock::now();
-    build_bvh(scene, config.has_split_method ? config.split_method : SplitMethod::Mid);  // integrator.rs:183-189
+    if (!device_build) build_bvh(scene, config.has_split_method ? config.split_method : SplitMethod::Mid);  // integrator.rs:183-189
     auto t2 = std::chrono::steady_clock::now();
     if (std::getenv("RT_HOST_VERBOSE"))
       std::fprintf(stderr, "rt_host: %zu elements expanded in %.3f s, BVH (%zu nodes, depth %d) built in %.3f s on up to %d threads\n",
@@ -110,6 +111,11 @@ class RenderIntegrator {
     prepared = true;
   }
 
+  // the scene on a device: the host's tree uploaded, or (device_build) the same tree built there from the primitives
+  int make_scene(int device, RtSceneHandle **out) {
+    return device_build ? rt_hip_scene_build(&pod, device, out) : rt_hip_scene_upload(&pod, device, out);
+  }
+
   // integrator.rs:161-249
   void render(int device, RtStats *stats) {
     prepare();
@@ -118,7 +124,7 @@ class RenderIntegrator {
       resident = nullptr;
     }
     if (!resident) {
-      if (rt_hip_scene_upload(&pod, device, &resident) != RT_OK) throw std::runtime_error(rt_hip_last_error());
+      if (make_scene(device, &resident) != RT_OK) throw std::runtime_error(rt_hip_last_error());
       resident_device = device;
     }
     RtConfig cfg = pod_config;
@@ -156,7 +162,7 @@ class RenderIntegrator {
     for (int r = 0; r < n; r++) {
       auto shard = [&, r] {
         try {
-          if (!shard_scenes[(size_t)r] && rt_hip_scene_upload(&pod, want[(size_t)r], &shard_scenes[(size_t)r]) != RT_OK) {
+          if (!shard_scenes[(size_t)r] && make_scene(want[(size_t)r], &shard_scenes[(size_t)r]) != RT_OK) {
             errors[(size_t)r] = rt_hip_last_error();
             return;
           }
@@ -358,7 +364,15 @@ int rt_host_prepare(RtHostIntegrator *h) {
 
 const RtScene *rt_host_scene(RtHostIntegrator *h) { return (h && h->impl->prepared) ? &h->impl->pod : nullptr; }
 RtConfig *rt_host_config(RtHostIntegrator *h) { return h ? &h->impl->pod_config : nullptr; }
-int rt_host_bvh_depth(RtHostIntegrator *h) { return (h && h->impl->prepared) ? h->impl->scene.bvh_depth : -1; }
+int rt_host_bvh_depth(RtHostIntegrator *h) { return (h && h->impl->prepared && !h->impl->device_build) ? h->impl->scene.bvh_depth : -1; }
+
+int rt_host_set_device_build(RtHostIntegrator *h, int on) {
+  return guarded([&] {
+    if (!h) throw std::runtime_error("null integrator");
+    if (h->impl->prepared) throw std::runtime_error("rt_host_set_device_build must be called before rt_host_prepare / rt_host_render");
+    h->impl->device_build = on != 0;
+  });
+}
 
 int rt_host_element_bbox(RtHostIntegrator *h, int element, double *min3, double *max3) {
   return guarded([&] {

@@ -156,6 +156,11 @@ class RenderIntegrator:
         except Exception:
             pass
 
+    def set_device_build(self, on=True):
+        """Before prepare(): leave the BVH build to the GPU (rt_host_set_device_build); render() then builds the same tree there."""
+        abi.check_host(abi.host_lib().rt_host_set_device_build(self._h, int(bool(on))))
+        return self
+
     # integrator.rs:163-192
     def prepare(self):
         abi.check_host(abi.host_lib().rt_host_prepare(self._h))

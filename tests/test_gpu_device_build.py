@@ -267,3 +267,21 @@ def test_device_build_rejects_what_it_cannot_build():
     s.spheres = sph
     assert lib.rt_hip_scene_build(C.byref(s), 0, C.byref(h)) == abi.RT_ERR_UNSUPPORTED and b"finite" in lib.rt_hip_last_error()
     assert lib.rt_hip_scene_build(C.byref(sc), 99, C.byref(h)) == abi.RT_ERR_BAD_ARG
+
+
+def test_host_integrator_can_leave_the_build_to_the_device(tmp_scene_dir):
+    """rt_host_set_device_build: render() of the host library with the tree built on the GPU gives the image of the default
+    path (the same tree; the Cornell scene's axis-aligned quads are bounded by the reference's boxes, so both walks agree)."""
+    import os
+    from helpers import knot_scene
+    a = knot_scene(tmp_scene_dir, 20000, 48, 48, 8, 3, 1)
+    a.render(0)
+    obj = os.path.join(tmp_scene_dir, "knot_20000.obj")
+    b = RenderIntegrator.new(scenes.scene_c3(obj), scenes.config(48, 48, 8, 3, 1)).set_device_build()
+    b.prepare()
+    assert b.bvh_depth() == -1 and b.scene.contents.n_nodes == 0
+    st = b.render(0)
+    assert st.rays > 0
+    assert np.array_equal(a.pixels, b.pixels) and np.array_equal(a.sample_pixels, b.sample_pixels)
+    with pytest.raises(abi.RtError):
+        b.set_device_build(False)                                  # too late: the integrator is prepared
