@@ -360,6 +360,9 @@ int rt_hip_scene_build(const RtScene *scene, int device, RtSceneHandle **out);
  *                       out->memory; the other outputs must be NULL); on the other ranks `out` may be NULL.  stats:
  *                       rays, samples, rays_traced and rays_by_depth are the job's totals on every rank, the rest is
  *                       the calling rank's.
+ * With id == NULL (and rank 0) rt_hip_comm_init makes a communicator that needs no RCCL and no second process: the one
+ * caller of rt_hip_render_ranks renders the shards of all `world` ranks in turn on its device and assembles them the same
+ * way -- for tests, and for trying a sharding out on one GPU.
  * The calls are collective and blocking: a rank that returns an error before the exchange (bad arguments, out of
  * memory) leaves the others waiting for it, so a caller that sees an error tears the job down, as with any RCCL program.
  * RCCL is loaded (dlopen) when the first id or communicator is made; a process that never calls these never loads it. */

@@ -117,14 +117,15 @@ static int comm_free_impl(RtComm *c) {
 
 static int comm_init_impl(const unsigned char *id, int rank, int world, int device, RtComm **out) {
   g_error.clear();
-  if (!id || !out) return fail(RT_ERR_BAD_ARG, "id or out is NULL");
+  if (!out) return fail(RT_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_BAD_ARG, "rank must lie in [0, world)");
+  if (!id && rank != 0) return fail(RT_ERR_BAD_ARG, "a communicator without an id plays every rank itself: its rank is 0");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(RT_ERR_BAD_ARG, "no such device");
-  const comm::Rccl *rccl;
-  int rc = comm::rccl_load(&rccl);
+  const comm::Rccl *rccl = nullptr;
+  int rc = id ? comm::rccl_load(&rccl) : RT_OK;  // id == NULL: no RCCL, the one process renders the ranks' shards in turn
   if (rc != RT_OK) return rc;
   HIP_TRY(hipSetDevice(device));
   RtComm *c = new (std::nothrow) RtComm;
@@ -141,9 +142,11 @@ static int comm_init_impl(const unsigned char *id, int rank, int world, int devi
   } unwind{c};
   HIP_TRY(hipStreamCreate(&c->stream));
   HIP_TRY(hipMalloc(&c->sums, 2 * kCommSums * sizeof(unsigned long long)));
-  ncclUniqueId u;
-  memcpy(&u, id, sizeof u);
-  RCCL_TRY(c, rccl->CommInitRank(&c->nccl, world, u, rank));
+  if (id) {
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(c, rccl->CommInitRank(&c->nccl, world, u, rank));
+  }
   unwind.c = nullptr;
   *out = c;
   return RT_OK;
@@ -198,16 +201,7 @@ static int render_ranks_impl(RtSceneHandle *h, RtComm *c, const RtConfig *cfg_in
   const int64_t w3 = 3 * (int64_t)cfg.img_width;
   const int64_t my_rows = comm_rows_of(H, B, c->rank, c->world);
   if (my_rows != shard_rows(&cfg)) return fail(RT_ERR_HIP, "row bookkeeping of the gather disagrees with the render's");
-  if ((rc = comm_grow(&c->mine, &c->mine_cap, (size_t)(2 * my_rows * w3))) != RT_OK) return rc;
-  RtStats local{};
-  if (my_rows > 0) {
-    RtImage img{};
-    img.pixels = c->mine;
-    img.sample_pixels = c->mine + my_rows * w3;
-    img.memory = RT_MEM_DEVICE;
-    if ((rc = render_resident_impl(h, &cfg, &img, &local)) != RT_OK) return rc;
-  }
-  // ---- every rank's rows to rank 0: one group of sends and receives
+  const bool loopback = c->nccl == nullptr && c->world > 1;  // this process plays every rank in turn
   std::vector<int64_t> rows((size_t)c->world), offset((size_t)c->world);
   int64_t total = 0;
   for (int r = 0; r < c->world; r++) {
@@ -218,9 +212,43 @@ static int render_ranks_impl(RtSceneHandle *h, RtComm *c, const RtConfig *cfg_in
   if (root) {
     if ((rc = comm_grow(&c->all, &c->all_cap, (size_t)total + 2 * (size_t)c->world)) != RT_OK) return rc;  // (+ room for the offsets and row counts)
     if ((rc = comm_grow(&c->image, &c->image_cap, (size_t)(2 * (int64_t)H * w3))) != RT_OK) return rc;
-    if (my_rows > 0) HIP_TRY(hipMemcpyAsync(c->all + offset[0], c->mine, (size_t)(2 * my_rows * w3) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
-  if (c->world > 1) {
+  RtStats local{};
+  if (loopback) {
+    for (int r = 0; r < c->world; r++) {
+      if (rows[(size_t)r] == 0) continue;
+      RtConfig cr = cfg;
+      cr.row_first = r;
+      RtImage img{};
+      img.pixels = c->all + offset[(size_t)r];
+      img.sample_pixels = img.pixels + rows[(size_t)r] * w3;
+      img.memory = RT_MEM_DEVICE;
+      RtStats part{};
+      if ((rc = render_resident_impl(h, &cr, &img, &part)) != RT_OK) return rc;
+      local.rays += part.rays;
+      local.samples += part.samples;
+      local.rays_traced += part.rays_traced;
+      for (int k = 0; k < RT_MAX_DEPTH_STATS; k++) local.rays_by_depth[k] += part.rays_by_depth[k];
+      local.trace_kernel_ms += part.trace_kernel_ms;
+      local.shade_kernel_ms += part.shade_kernel_ms;
+      local.other_kernel_ms += part.other_kernel_ms;
+      local.trace_launches += part.trace_launches;
+      local.batches = std::max(local.batches, part.batches);
+    }
+  } else {
+    if ((rc = comm_grow(&c->mine, &c->mine_cap, (size_t)(2 * my_rows * w3))) != RT_OK) return rc;
+    if (my_rows > 0) {
+      RtImage img{};
+      img.pixels = c->mine;
+      img.sample_pixels = c->mine + my_rows * w3;
+      img.memory = RT_MEM_DEVICE;
+      if ((rc = render_resident_impl(h, &cfg, &img, &local)) != RT_OK) return rc;
+    }
+    if (root && my_rows > 0)
+      HIP_TRY(hipMemcpyAsync(c->all + offset[0], c->mine, (size_t)(2 * my_rows * w3) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  // ---- every rank's rows to rank 0: one group of sends and receives
+  if (c->world > 1 && !loopback) {
     RCCL_TRY(c, c->rccl->GroupStart());
     if (root) {
       for (int r = 1; r < c->world; r++)
@@ -234,7 +262,7 @@ static int render_ranks_impl(RtSceneHandle *h, RtComm *c, const RtConfig *cfg_in
   unsigned long long host_sums[kCommSums] = {local.rays, local.samples, local.rays_traced};
   for (int k = 0; k < RT_MAX_DEPTH_STATS; k++) host_sums[3 + k] = local.rays_by_depth[k];
   HIP_TRY(hipMemcpyAsync(c->sums, host_sums, sizeof host_sums, hipMemcpyHostToDevice, c->stream));
-  if (c->world > 1) RCCL_TRY(c, c->rccl->AllReduce(c->sums, c->sums + kCommSums, kCommSums, ncclUint64, ncclSum, c->nccl, c->stream));
+  if (c->world > 1 && !loopback) RCCL_TRY(c, c->rccl->AllReduce(c->sums, c->sums + kCommSums, kCommSums, ncclUint64, ncclSum, c->nccl, c->stream));
   else HIP_TRY(hipMemcpyAsync(c->sums + kCommSums, c->sums, sizeof host_sums, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(host_sums, c->sums + kCommSums, sizeof host_sums, hipMemcpyDeviceToHost, c->stream));
   // ---- rank 0 puts the image together and hands it over

@@ -116,7 +116,7 @@ class RankComm:
     def __init__(self, comm_id, rank, world, device):
         import ctypes as C
         from . import abi
-        assert len(comm_id) == abi.RT_COMM_ID_BYTES
+        assert comm_id is None or len(comm_id) == abi.RT_COMM_ID_BYTES  # None: this process plays every rank in turn (no RCCL)
         self._c = C.c_void_p()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
         abi.check_hip(abi.hip_lib().rt_hip_comm_init(comm_id, self.rank, self.world, self.device, C.byref(self._c)))

@@ -55,3 +55,20 @@ def test_render_ranks_rejects_what_it_cannot_gather():
     assert lib.rt_hip_render_ranks(res._h, comm._c, C.byref(cfg), C.byref(img), C.byref(stats)) == abi.RT_ERR_UNSUPPORTED
     assert b"render_line" in lib.rt_hip_last_error()
     comm.close()
+
+
+@pytest.mark.parametrize("world,block", [(2, 1), (3, 1), (4, 8), (5, 2), (40, 1)])
+def test_one_process_playing_every_rank_assembles_the_single_process_image(world, block):
+    """A communicator made without an id renders the shards of all ranks in turn and puts them together exactly as rank 0 of a
+    real job does (same row bookkeeping, same assembly kernel): the image must be the single-process one for any number of
+    ranks and any block size, also when some ranks get no row at all (40 ranks, 33 rows)."""
+    ri = c1(width=40, height=33, batch=8, max_batches=5, min_batches=1)
+    res = ri.resident(0)
+    comm = parallel.RankComm(None, 0, world, 0)
+    cfg = ri.config.copy()
+    cfg.row_block = block
+    out, st = comm.render(res, cfg)
+    one, st1 = res.render(ri.config.copy())
+    assert np.array_equal(out["pixels"], one["pixels"]) and np.array_equal(out["sample_pixels"], one["sample_pixels"])
+    assert st.rays == st1.rays and st.samples == st1.samples
+    comm.close()
